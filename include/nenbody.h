@@ -1,0 +1,138 @@
+/*
+ * nenbody.h -- C ABI of libnenbody_hip.so: nenbody's all-pairs gravity + Euler step on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of Dasch0/nenbody: `update_instance_nbody`
+ * (reference src/main.rs:404-441), the body of the `Scene::step()` the reference's empty
+ * `src/scene.rs` (src/scene.rs:1, declared at src/main.rs:2) was evidently meant to hold.
+ * The reference has no FFI of its own; each entry point below cites the reference
+ * interface it stands in for.  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * `Scene` shim a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types.
+ *  - every function returns NB_OK (0) or a negative nb_status; nothing unwinds across the boundary.
+ *  - host arrays are caller-allocated, caller-freed, and never retained past the call.
+ *  - positions / velocities cross as AoS stride-3 float arrays (x,y,z): the in-memory form of
+ *    Vec<cgmath::Point3<f32>> / Vec<cgmath::Vector3<f32>>, so `positions.as_ptr() as *const f32` needs no repack.
+ *  - instance matrices cross as 16 floats per body, column-major: the in-memory form of
+ *    Vec<[[f32; 4]; 4]> consumed as `mat4 model[]` by shaders/scene.vert:12-14,18.
+ *  - a context is single-owner and not re-entrant (the reference calls the update on the winit main
+ *    thread, src/main.rs:925); work is queued on a HIP stream and nb_step may return before it finishes.
+ *  - there is NO CPU fallback: without a HIP device every compute entry point fails with NB_ERR_NO_DEVICE.
+ */
+#ifndef NENBODY_H
+#define NENBODY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_ABI_VERSION 1
+
+typedef enum nb_status {
+    NB_OK = 0,
+    NB_ERR_INVALID = -1,     /* bad argument (null pointer, zero bodies, range outside the set, bad mode/tile) */
+    NB_ERR_NO_DEVICE = -2,   /* no HIP device visible / HIP runtime failed to initialise */
+    NB_ERR_HIP = -3,         /* a HIP call failed; nb_last_error() has the HIP error string */
+    NB_ERR_ALLOC = -4,       /* device or host allocation failed */
+    NB_ERR_STATE = -5,       /* call sequence error (e.g. nb_step before nb_upload) */
+    NB_ERR_UNSUPPORTED = -6  /* e.g. n_devices != 1: one process drives one GPU; see nb_launch_step for sharding */
+} nb_status;
+
+/* Arithmetic variants of the pair fold (src/main.rs:425-432). */
+typedef enum nb_mode {
+    /* Bit-identical to the reference's binary32 arithmetic: sequential j = 0..N-1 per body, no FMA
+     * contraction, correctly rounded (vec*G)/dist per component.  The parity path. */
+    NB_MODE_STRICT = 0,
+    /* Same law, reassociated for speed: r2 by FMA chain, v_rcp_f32 instead of the divide, G hoisted out
+     * of the sum, j range may be split and partial sums combined in a fixed (deterministic) order.
+     * Per-step relative force error ~1e-6; NOT bit-identical to the reference. */
+    NB_MODE_FAST = 1
+} nb_mode;
+
+/* Constants of the step.  Defaults are the reference's: src/main.rs:411-413. */
+typedef struct nb_params {
+    float dt;       /* 0.1       main.rs:411 (velocity update only; position advances by v with no dt, main.rs:436) */
+    float G;        /* 0.001     main.rs:412 */
+    float bias;     /* 0.0000001 main.rs:413, added to the squared distance */
+    uint32_t tile;  /* bodies staged through LDS per tile; 0 = library default; else 256, 512 or 1024 */
+    uint32_t mode;  /* nb_mode */
+} nb_params;
+
+typedef struct nb_ctx nb_ctx; /* opaque; owns the device buffers and the stream */
+
+/* -- library ------------------------------------------------------------------------------------------- */
+int nb_abi_version(void);
+/* Fills *p with the reference constants (main.rs:411-413), tile 0, NB_MODE_STRICT. */
+void nb_default_params(nb_params *p);
+/* Number of HIP devices this process can see, or a negative nb_status. */
+int nb_device_count(void);
+/* Message of the last failure on `ctx`, or (ctx == NULL) of the calling thread's last failed
+ * context-free call.  Never NULL; valid until the next call on the same ctx / thread. */
+const char *nb_last_error(const nb_ctx *ctx);
+
+/* Seeded stand-in for the reference's unseeded rand::thread_rng() initial state (src/main.rs:736-747):
+ * same distributions and draw order (all velocities (U[0,0.1),U[0,0.1),0) first, then all positions
+ * (U[-100,100),U[-100,100),0)).  Host-side; pos_xyz / vel_xyz hold 3*n floats. */
+int nb_init_state(uint64_t seed, uint32_t n, float *pos_xyz, float *vel_xyz);
+
+/* -- context API: what a Scene owns -------------------------------------------------------------------- *
+ * Stands in for the state the reference keeps in main(): positions, velocities, old_positions,
+ * old_velocities, instance_data (src/main.rs:738-750) -- here device-resident.                            */
+
+/* Create a context for n bodies on the current HIP device.  n_devices must be 1 (one process per GPU;
+ * multi-GPU hosts shard with nb_launch_step + an all-gather, see below).  params == NULL -> defaults. */
+int nb_create(uint32_t n, uint32_t n_devices, const nb_params *params, nb_ctx **out);
+void nb_destroy(nb_ctx *ctx);
+
+/* Host -> device.  pos_xyz, vel_xyz: 3*n floats each (the Vec<Point3>/Vec<Vector3> the reference's
+ * update function receives, src/main.rs:406-408). */
+int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz);
+
+/* k applications of update_instance_nbody (src/main.rs:404-441), device-resident, asynchronous.
+ * old_positions (main.rs:415) is the ping-pong buffer; old_velocities (main.rs:416) is never read by
+ * the reference's function and has no counterpart. */
+int nb_step(nb_ctx *ctx, uint32_t k);
+
+/* Device -> host, after waiting for queued steps.  Any of the three may be NULL.
+ * inst_16n, when given, receives the model matrices of the current state (src/main.rs:437-439),
+ * produced on demand by a separate kernel: they never feed back into the dynamics. */
+int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *inst_16n);
+
+/* Block until all queued work of ctx has finished. */
+int nb_sync(nb_ctx *ctx);
+
+/* Steps taken since nb_upload. */
+uint64_t nb_steps_done(const nb_ctx *ctx);
+
+/* -- launch API: caller-owned device memory ------------------------------------------------------------ *
+ * For hosts that own the device buffers and the exchange step themselves (one process per GPU, RCCL
+ * all-gather of positions between steps).  Device layout: one 16-byte record per body,
+ * float4 (x, y, z, 0) for positions and (vx, vy, vz, 0) for velocities.
+ * `stream` is a hipStream_t (NULL = the default stream).  All launches are asynchronous.                 */
+
+/* Bytes of device scratch nb_launch_step needs for this shape (may be 0). */
+size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count);
+
+/* One step for bodies [first, first+count) of a set of n_total:
+ *   pos_in   n_total records, the start-of-step snapshot (old_positions, main.rs:415), read only
+ *   pos_out  n_total records; only [first, first+count) is written (the caller gathers the rest)
+ *   vel      count records, this shard's velocities, updated in place (local index i - first)
+ * pos_out must not alias pos_in. */
+int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                   void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream);
+
+/* Model matrices (main.rs:437-439) for `count` bodies: pos, vel -> inst (16 floats per body). */
+int nb_launch_instances(uint32_t count, const void *pos, const void *vel, void *inst_16n, void *stream);
+
+/* Stride-3 <-> 16-byte record conversion on the device. */
+int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream);
+int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NENBODY_H */

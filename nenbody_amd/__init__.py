@@ -1,0 +1,12 @@
+"""nenbody_amd -- MI355X-native implementation of nenbody's all-pairs gravity + Euler step.
+
+One path only: ``update_instance_nbody`` (reference src/main.rs:404-441), behind a C ABI
+(include/nenbody.h, libnenbody_hip.so).  This package is the thin host side: a ctypes binding, a
+``Scene`` that mirrors the reference's update interface, and a sharded scene for one process per GPU.
+"""
+from ._lib import (NB_MODE_FAST, NB_MODE_STRICT, NbError, NbParams, default_params, load)  # noqa: F401
+from .scene import Scene, init_state, update_instance_nbody  # noqa: F401
+from .dist import ShardedScene, partition  # noqa: F401
+
+__all__ = ["Scene", "ShardedScene", "partition", "init_state", "update_instance_nbody", "default_params", "load",
+           "NbParams", "NbError", "NB_MODE_STRICT", "NB_MODE_FAST"]

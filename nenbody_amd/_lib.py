@@ -1,0 +1,120 @@
+"""ctypes binding of libnenbody_hip.so (the C ABI declared in include/nenbody.h).
+
+The library is the product; this module only loads it and declares prototypes.  There is no
+Python or CPU implementation of the step to fall back to: if the shared object is missing the import
+of the binding fails loudly, and on a machine without a HIP device every compute entry point returns
+NB_ERR_NO_DEVICE, surfaced here as :class:`NbError`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnenbody_hip.so")
+
+NB_ABI_VERSION = 1
+NB_OK = 0
+NB_ERR_INVALID = -1
+NB_ERR_NO_DEVICE = -2
+NB_ERR_HIP = -3
+NB_ERR_ALLOC = -4
+NB_ERR_STATE = -5
+NB_ERR_UNSUPPORTED = -6
+
+NB_MODE_STRICT = 0
+NB_MODE_FAST = 1
+
+_STATUS_NAMES = {
+    NB_ERR_INVALID: "NB_ERR_INVALID",
+    NB_ERR_NO_DEVICE: "NB_ERR_NO_DEVICE",
+    NB_ERR_HIP: "NB_ERR_HIP",
+    NB_ERR_ALLOC: "NB_ERR_ALLOC",
+    NB_ERR_STATE: "NB_ERR_STATE",
+    NB_ERR_UNSUPPORTED: "NB_ERR_UNSUPPORTED",
+}
+
+
+class NbParams(ctypes.Structure):
+    """struct nb_params (include/nenbody.h); defaults are the reference's src/main.rs:411-413."""
+
+    _fields_ = [("dt", c_float), ("G", c_float), ("bias", c_float), ("tile", c_uint32), ("mode", c_uint32)]
+
+    def __repr__(self) -> str:  # pragma: no cover - debugging aid
+        return f"NbParams(dt={self.dt}, G={self.G}, bias={self.bias}, tile={self.tile}, mode={self.mode})"
+
+
+class NbError(RuntimeError):
+    """A non-zero nb_status from the library."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        super().__init__(f"{_STATUS_NAMES.get(status, status)}: {message}")
+
+
+# every symbol include/nenbody.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "nb_abi_version": (c_int, []),
+    "nb_default_params": (None, [POINTER(NbParams)]),
+    "nb_device_count": (c_int, []),
+    "nb_last_error": (c_char_p, [c_void_p]),
+    "nb_init_state": (c_int, [c_uint64, c_uint32, c_void_p, c_void_p]),
+    "nb_create": (c_int, [c_uint32, c_uint32, POINTER(NbParams), POINTER(c_void_p)]),
+    "nb_destroy": (None, [c_void_p]),
+    "nb_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nb_step": (c_int, [c_void_p, c_uint32]),
+    "nb_download": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_sync": (c_int, [c_void_p]),
+    "nb_steps_done": (c_uint64, [c_void_p]),
+    "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),
+    "nb_launch_step": (
+        c_int,
+        [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
+    "nb_launch_unpack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libnenbody_hip.so (built by nenbody_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C nenbody_amd/csrc` (hipcc, gfx950). "
+            "nenbody_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.nb_abi_version()
+    if got != NB_ABI_VERSION:
+        raise ImportError(f"libnenbody_hip.so ABI {got} != binding ABI {NB_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def default_params(mode: int = NB_MODE_STRICT, tile: int = 0) -> NbParams:
+    p = NbParams()
+    load().nb_default_params(ctypes.byref(p))
+    p.mode = mode
+    p.tile = tile
+    return p
+
+
+def last_error(ctx=None) -> str:
+    msg = load().nb_last_error(ctx)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int, ctx=None) -> None:
+    if status != NB_OK:
+        raise NbError(status, last_error(ctx))

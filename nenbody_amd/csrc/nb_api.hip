@@ -1,0 +1,492 @@
+// nb_api.hip -- the extern "C" boundary declared in include/nenbody.h.
+//
+// Host-side only: argument checking, launch-shape selection, device buffers of a context.  There is no
+// CPU implementation of the step in this library: without a HIP device every compute call fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/nenbody.h"
+#include "nb_kernels.h"
+
+#define NB_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_tls_error = "";
+
+// MI355X: 256 CUs x 4 SIMDs.  FAST launches aim at >= 4 waves per SIMD.
+constexpr uint32_t kTargetWaves = 4096;
+constexpr uint32_t kMaxSlices = 64;
+
+int env_u32(const char *name, uint32_t *out)
+{
+    const char *s = std::getenv(name);
+    if (!s || !*s) return 0;
+    *out = (uint32_t)std::strtoul(s, nullptr, 10);
+    return 1;
+}
+
+bool valid_tile(uint32_t t) { return t == 256 || t == 512 || t == 1024; }
+
+struct Plan {
+    uint32_t tile;
+    uint32_t ib;      // FAST: bodies per thread
+    uint32_t slices;  // FAST: blockIdx.y slices of the j range
+    uint32_t j_chunk;
+    uint32_t lo_bits, hi_bits, force_ieee;  // STRICT guard
+};
+
+int floor_log2f(float x)
+{
+    int e;
+    std::frexp(x, &e);  // x = m * 2^e, m in [0.5, 1)
+    return e - 1;
+}
+
+// Launch shape + STRICT guard range for (params, n_total, count).  Pure host arithmetic.
+int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, std::string *err)
+{
+    if (n_total == 0 || count == 0 || count > n_total) {
+        *err = "nb: need 0 < count <= n_total";
+        return NB_ERR_INVALID;
+    }
+    if (p.mode != NB_MODE_STRICT && p.mode != NB_MODE_FAST) {
+        *err = "nb: params.mode must be NB_MODE_STRICT or NB_MODE_FAST";
+        return NB_ERR_INVALID;
+    }
+    Plan pl{};
+    pl.tile = p.tile;
+    if (pl.tile == 0) {
+        pl.tile = (p.mode == NB_MODE_STRICT) ? 256u : 512u;
+        env_u32("NB_TILE", &pl.tile);
+    }
+    if (!valid_tile(pl.tile)) {
+        *err = "nb: params.tile must be 0, 256, 512 or 1024";
+        return NB_ERR_INVALID;
+    }
+    pl.ib = 1;
+    pl.slices = 1;
+    pl.j_chunk = n_total;
+    if (p.mode == NB_MODE_FAST) {
+        pl.ib = (count >= 65536u) ? 2u : 1u;
+        env_u32("NB_FAST_IB", &pl.ib);
+        if (pl.ib != 1 && pl.ib != 2 && pl.ib != 4) pl.ib = 1;
+        const uint32_t blocks = (count + 256u * pl.ib - 1u) / (256u * pl.ib);
+        uint32_t slices = (kTargetWaves + blocks * 4u - 1u) / (blocks * 4u);
+        env_u32("NB_FAST_SLICES", &slices);
+        const uint32_t max_by_tiles = (n_total + pl.tile - 1u) / pl.tile;
+        if (slices > max_by_tiles) slices = max_by_tiles;
+        if (slices > kMaxSlices) slices = kMaxSlices;
+        if (slices < 1) slices = 1;
+        uint32_t chunk = (n_total + slices - 1u) / slices;
+        chunk = ((chunk + pl.tile - 1u) / pl.tile) * pl.tile;
+        slices = (n_total + chunk - 1u) / chunk;  // drop empty slices
+        pl.slices = slices;
+        pl.j_chunk = chunk;
+    }
+    // STRICT: magnitude range {0} U [2^a, 2^b] of coordinates for which d, n = dx*G, q = n/d and the
+    // ladder's residuals are all normal binary32 with headroom, so that v_div_scale/v_div_fixup would be
+    // the identity and the shared-reciprocal ladder equals the IEEE divide bit for bit.
+    //   nonzero |dx| >= 2^(a-23), |dx| <= 2^(b+1);  d in [bias, 3*2^(2b+2)+bias];  |n| >= 2^(a-23+g)
+    pl.force_ieee = 1;
+    pl.lo_bits = 0x3f800000u;
+    pl.hi_bits = 0x3f800000u;
+    const float G = std::fabs(p.G);
+    if (std::isfinite(p.G) && std::isfinite(p.bias) && G > 0.f && p.bias > 0.f) {
+        const int g = floor_log2f(G), c = floor_log2f(p.bias);
+        const int b = 20;
+        const int dmax = std::max(2 * b + 4, c + 2);
+        int a = std::max(-100 + 23 - g, -120 + 23 - g + dmax);
+        const bool ok = g >= -100 && g <= 100 && c >= -100 && dmax <= 100 && (b + 2 + g - c) <= 120 && a <= b - 1;
+        if (ok) {
+            if (a < -120) a = -120;
+            pl.lo_bits = (uint32_t)(a + 127) << 23;
+            pl.hi_bits = (uint32_t)(b + 127) << 23;
+            pl.force_ieee = 0;
+        }
+    }
+    uint32_t f = 0;
+    if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
+    *out = pl;
+    return NB_OK;
+}
+
+size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
+{
+    return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
+}
+
+int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, uint32_t first, uint32_t count,
+                        const void *pos_in, void *pos_out, void *vel, void *scratch, hipStream_t stream, std::string *err)
+{
+    nbk::StepArgs a{};
+    a.pos_in = (const float4 *)pos_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel = (float4 *)vel;
+    a.partial = (float4 *)scratch;
+    a.n_total = n_total;
+    a.first = first;
+    a.count = count;
+    a.dt = p.dt;
+    a.G = p.G;
+    a.bias = p.bias;
+    a.lo_bits = pl.lo_bits;
+    a.hi_bits = pl.hi_bits;
+    a.force_ieee = pl.force_ieee;
+    a.j_chunk = pl.j_chunk;
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? nbk::launch_strict(a, pl.tile, stream)
+                                              : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
+    if (e != hipSuccess) {
+        *err = std::string("nb: kernel launch failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+
+int check_device(std::string *err)
+{
+    static bool seen = false;  // a device does not disappear; cache only the positive answer
+    if (seen) return NB_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        *err = std::string("nb: no HIP device available (") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+               "); this library has no CPU path";
+        return NB_ERR_NO_DEVICE;
+    }
+    seen = true;
+    return NB_OK;
+}
+
+uint64_t splitmix64(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+float uniform_f32(uint64_t &s, float lo, float hi)
+{
+    const uint32_t bits24 = (uint32_t)(splitmix64(s) >> 40);
+    const float u = (float)bits24 * 0x1.0p-24f;
+    const float scale = hi - lo;
+    const float v = scale * u;
+    return lo + v;
+}
+
+}  // namespace
+
+struct nb_ctx {
+    uint32_t n = 0;
+    nb_params p{};
+    Plan plan{};
+    hipStream_t stream = nullptr;
+    float4 *pos[2] = {nullptr, nullptr};
+    float4 *vel = nullptr;
+    float *stage = nullptr;   // 3n floats: stride-3 staging for upload/download
+    float4 *inst = nullptr;   // 4n float4, allocated on first use
+    void *scratch = nullptr;
+    int cur = 0;
+    bool uploaded = false;
+    uint64_t steps = 0;
+    std::string err;
+};
+
+#define NB_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string("nb: " #call " failed: ") + hipGetErrorString(e_);            \
+            return (e_ == hipErrorOutOfMemory) ? NB_ERR_ALLOC : NB_ERR_HIP;                        \
+        }                                                                                          \
+    } while (0)
+
+NB_EXPORT int nb_abi_version(void) { return NB_ABI_VERSION; }
+
+NB_EXPORT void nb_default_params(nb_params *p)
+{
+    if (!p) return;
+    p->dt = 0.1f;          // main.rs:411
+    p->G = 0.001f;         // main.rs:412
+    p->bias = 0.0000001f;  // main.rs:413
+    p->tile = 0;
+    p->mode = NB_MODE_STRICT;
+}
+
+NB_EXPORT int nb_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_tls_error = std::string("nb: hipGetDeviceCount failed: ") + hipGetErrorString(e);
+        return NB_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+NB_EXPORT const char *nb_last_error(const nb_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_error.c_str(); }
+
+NB_EXPORT int nb_init_state(uint64_t seed, uint32_t n, float *pos_xyz, float *vel_xyz)
+{
+    if (!pos_xyz || !vel_xyz) {
+        g_tls_error = "nb_init_state: null array";
+        return NB_ERR_INVALID;
+    }
+    uint64_t s = seed;
+    for (uint32_t i = 0; i < n; ++i) {  // main.rs:738-742
+        vel_xyz[3 * (size_t)i + 0] = uniform_f32(s, -0.0f, 0.1f);
+        vel_xyz[3 * (size_t)i + 1] = uniform_f32(s, -0.0f, 0.1f);
+        vel_xyz[3 * (size_t)i + 2] = 0.0f;
+    }
+    for (uint32_t i = 0; i < n; ++i) {  // main.rs:743-747
+        pos_xyz[3 * (size_t)i + 0] = uniform_f32(s, -100.0f, 100.0f);
+        pos_xyz[3 * (size_t)i + 1] = uniform_f32(s, -100.0f, 100.0f);
+        pos_xyz[3 * (size_t)i + 2] = 0.0f;
+    }
+    return NB_OK;
+}
+
+NB_EXPORT void nb_destroy(nb_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pos[0]) (void)hipFree(ctx->pos[0]);
+    if (ctx->pos[1]) (void)hipFree(ctx->pos[1]);
+    if (ctx->vel) (void)hipFree(ctx->vel);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->inst) (void)hipFree(ctx->inst);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(nb_ctx *c)
+{
+    const size_t rec = (size_t)c->n * sizeof(float4);
+    NB_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    NB_HIP(c, hipMalloc((void **)&c->pos[0], rec));
+    NB_HIP(c, hipMalloc((void **)&c->pos[1], rec));
+    NB_HIP(c, hipMalloc((void **)&c->vel, rec));
+    NB_HIP(c, hipMalloc((void **)&c->stage, (size_t)c->n * 3 * sizeof(float)));
+    const size_t sb = plan_scratch_bytes(c->plan, c->n);
+    if (sb) NB_HIP(c, hipMalloc(&c->scratch, sb));
+    return NB_OK;
+}
+
+NB_EXPORT int nb_create(uint32_t n, uint32_t n_devices, const nb_params *params, nb_ctx **out)
+{
+    if (!out) {
+        g_tls_error = "nb_create: out is null";
+        return NB_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (n_devices != 1) {
+        g_tls_error =
+            "nb_create: n_devices must be 1 (one process drives one GPU; shard with nb_launch_step and an all-gather)";
+        return NB_ERR_UNSUPPORTED;
+    }
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    Plan plan;
+    int rc = make_plan(p, n, n, &plan, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    nb_ctx *c = new (std::nothrow) nb_ctx();
+    if (!c) {
+        g_tls_error = "nb_create: out of host memory";
+        return NB_ERR_ALLOC;
+    }
+    c->n = n;
+    c->p = p;
+    c->plan = plan;
+    rc = create_impl(c);
+    if (rc != NB_OK) {
+        g_tls_error = c->err;
+        nb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return NB_OK;
+}
+
+NB_EXPORT int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz)
+{
+    if (!ctx) {
+        g_tls_error = "nb_upload: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!pos_xyz || !vel_xyz) {
+        ctx->err = "nb_upload: null array";
+        return NB_ERR_INVALID;
+    }
+    const size_t bytes = (size_t)ctx->n * 3 * sizeof(float);
+    ctx->cur = 0;
+    NB_HIP(ctx, hipMemcpyAsync(ctx->stage, pos_xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->stage, ctx->pos[0], ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // stage is reused; the host array is not retained
+    NB_HIP(ctx, hipMemcpyAsync(ctx->stage, vel_xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->stage, ctx->vel, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->uploaded = true;
+    ctx->steps = 0;
+    return NB_OK;
+}
+
+NB_EXPORT int nb_step(nb_ctx *ctx, uint32_t k)
+{
+    if (!ctx) {
+        g_tls_error = "nb_step: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_step: no state uploaded (call nb_upload first)";
+        return NB_ERR_STATE;
+    }
+    for (uint32_t s = 0; s < k; ++s) {
+        int rc = launch_step_planned(ctx->p, ctx->plan, ctx->n, 0, ctx->n, ctx->pos[ctx->cur], ctx->pos[ctx->cur ^ 1],
+                                     ctx->vel, ctx->scratch, ctx->stream, &ctx->err);
+        if (rc != NB_OK) return rc;
+        ctx->cur ^= 1;
+        ctx->steps++;
+    }
+    return NB_OK;
+}
+
+NB_EXPORT int nb_sync(nb_ctx *ctx)
+{
+    if (!ctx) {
+        g_tls_error = "nb_sync: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NB_OK;
+}
+
+NB_EXPORT uint64_t nb_steps_done(const nb_ctx *ctx) { return ctx ? ctx->steps : 0; }
+
+NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *inst_16n)
+{
+    if (!ctx) {
+        g_tls_error = "nb_download: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_download: no state uploaded";
+        return NB_ERR_STATE;
+    }
+    const size_t bytes = (size_t)ctx->n * 3 * sizeof(float);
+    if (pos_xyz) {
+        NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->stage, ctx->stream));
+        NB_HIP(ctx, hipMemcpyAsync(pos_xyz, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (vel_xyz) {
+        NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->vel, ctx->stage, ctx->stream));
+        NB_HIP(ctx, hipMemcpyAsync(vel_xyz, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (inst_16n) {
+        if (!ctx->inst) NB_HIP(ctx, hipMalloc((void **)&ctx->inst, (size_t)ctx->n * 16 * sizeof(float)));
+        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream));
+        NB_HIP(ctx, hipMemcpyAsync(inst_16n, ctx->inst, (size_t)ctx->n * 16 * sizeof(float), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (!pos_xyz && !vel_xyz && !inst_16n) NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NB_OK;
+}
+
+// ---- launch API -----------------------------------------------------------------------------------------
+
+NB_EXPORT size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    Plan pl;
+    std::string err;
+    if (make_plan(p, n_total, count, &pl, &err) != NB_OK) return 0;
+    return plan_scratch_bytes(pl, count);
+}
+
+NB_EXPORT int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                             void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    if (!pos_in || !pos_out || !vel || pos_in == pos_out) {
+        g_tls_error = "nb_launch_step: pos_in, pos_out, vel must be non-null and pos_out must not alias pos_in";
+        return NB_ERR_INVALID;
+    }
+    if ((uint64_t)first + (uint64_t)count > (uint64_t)n_total) {
+        g_tls_error = "nb_launch_step: [first, first+count) exceeds n_total";
+        return NB_ERR_INVALID;
+    }
+    Plan pl;
+    int rc = make_plan(p, n_total, count, &pl, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    const size_t need = plan_scratch_bytes(pl, count);
+    if (need && (!scratch || scratch_bytes < need)) {
+        g_tls_error = "nb_launch_step: scratch smaller than nb_scratch_bytes()";
+        return NB_ERR_INVALID;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    return launch_step_planned(p, pl, n_total, first, count, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+#define NB_LAUNCH_TLS(call)                                                                  \
+    do {                                                                                     \
+        int rc_ = check_device(&g_tls_error);                                                \
+        if (rc_ != NB_OK) return rc_;                                                        \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            g_tls_error = std::string("nb: " #call " failed: ") + hipGetErrorString(e_);     \
+            return NB_ERR_HIP;                                                               \
+        }                                                                                    \
+        return NB_OK;                                                                        \
+    } while (0)
+
+NB_EXPORT int nb_launch_instances(uint32_t count, const void *pos, const void *vel, void *inst_16n, void *stream)
+{
+    if (!count || !pos || !vel || !inst_16n) {
+        g_tls_error = "nb_launch_instances: bad argument";
+        return NB_ERR_INVALID;
+    }
+    NB_LAUNCH_TLS(nbk::launch_instances(count, (const float4 *)pos, (const float4 *)vel, (float4 *)inst_16n, (hipStream_t)stream));
+}
+
+NB_EXPORT int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream)
+{
+    if (!count || !xyz || !rec4) {
+        g_tls_error = "nb_launch_pack: bad argument";
+        return NB_ERR_INVALID;
+    }
+    NB_LAUNCH_TLS(nbk::launch_pack(count, (const float *)xyz, (float4 *)rec4, (hipStream_t)stream));
+}
+
+NB_EXPORT int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void *stream)
+{
+    if (!count || !rec4 || !xyz) {
+        g_tls_error = "nb_launch_unpack: bad argument";
+        return NB_ERR_INVALID;
+    }
+    NB_LAUNCH_TLS(nbk::launch_unpack(count, (const float4 *)rec4, (float *)xyz, (hipStream_t)stream));
+}

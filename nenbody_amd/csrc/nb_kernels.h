@@ -1,0 +1,27 @@
+// nb_kernels.h -- internal interface between the C ABI (nb_api.hip) and the kernels (nb_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbk {
+
+// Arguments of one step for bodies [first, first+count) of a set of n_total.
+struct StepArgs {
+    const float4 *pos_in;  // n_total records (x,y,z,0): the start-of-step snapshot (old_positions, main.rs:415)
+    float4 *pos_out;       // n_total records; [first, first+count) written
+    float4 *vel;           // count records, local index, updated in place
+    float4 *partial;       // FAST with a split j range: [slices][count] partial sums
+    uint32_t n_total, first, count;
+    float dt, G, bias;     // main.rs:411-413
+    uint32_t lo_bits, hi_bits;  // STRICT: bit patterns of the magnitude range where the unscaled divide ladder is exact
+    uint32_t force_ieee;        // STRICT: 1 = always take the IEEE '/' path (parameters outside the proven range; tests)
+    uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
+};
+
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, hipStream_t s);
+hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
+hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
+hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
+hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
+
+}  // namespace nbk

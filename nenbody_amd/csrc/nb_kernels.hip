@@ -1,0 +1,443 @@
+// nb_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for nenbody's all-pairs gravity + Euler step.
+//
+// Path: update_instance_nbody, reference src/main.rs:404-441.  Per body n, against the
+// start-of-step snapshot of all positions (old_positions, main.rs:415):
+//     a_n = sum_{i=0..N-1} ((p_i - p_n) * G) / (|p_i - p_n|^2 + bias)      main.rs:425-432 (i == n included)
+//     v_n = v_n + a_n * dt                                                  main.rs:434
+//     p_n = v_n + p_n                      (new v, no dt)                   main.rs:436
+//     M_n = T(p_n) * Rz(atan2(v_n.y, v_n.x))                                main.rs:437-439, 141-143
+//
+// Mapping to the hardware (one thread per body, 64-lane waves, 256-thread workgroups):
+//   - the j loop is tiled through LDS: a workgroup stages TJ 16-byte position records per tile
+//     (coalesced global_load_dwordx4 -> ds_write_b128, double buffered, one barrier per tile);
+//     every lane then walks the tile IN INDEX ORDER reading the same LDS address (a broadcast:
+//     no bank conflict), so each wave-instruction evaluates 64 pairs.
+//   - the work is fp32 VALU (no MFMA: pairwise math, not a contraction); HBM traffic is 48 B per
+//     body per step against 18*N flop per body, so the kernel is VALU-issue bound.
+//   - STRICT: the reference's exact binary32 operation order.  The three divides by the same
+//     denominator share one v_rcp_f32 + Newton step and then run the same FMA correction ladder the
+//     compiler's IEEE divide expands to (see div3_shared below); a per-tile range guard falls back to
+//     the plain IEEE '/' where the unscaled ladder would not be exact.  Result: bit-identical.
+//   - FAST: FMA chain for r^2, v_rcp_f32 for the divide, G hoisted, IB bodies per thread to amortise
+//     the LDS reads, j range optionally split over blockIdx.y with a fixed-order combine.
+//
+// This translation unit is compiled with -ffp-contract=off: every fused multiply-add below is an
+// explicit __builtin_fmaf, every unfused a*b+c stays two roundings.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nb_kernels.h"
+
+namespace nbk {
+
+static constexpr int kBlock = 256;   // threads per workgroup = 4 waves, one per SIMD of a CU
+static constexpr int kWaves = kBlock / 64;
+
+// ------------------------------------------------------------------------------------------------
+// tile staging: global -> registers -> LDS, TJ records per tile, TJ/256 per thread
+// ------------------------------------------------------------------------------------------------
+template <int TJ>
+struct TileRegs {
+    float4 r[TJ / kBlock];
+};
+
+template <int TJ>
+__device__ __forceinline__ void tile_fetch(TileRegs<TJ> &t, const float4 *__restrict__ pos, uint32_t j0, uint32_t jend,
+                                           int tid)
+{
+#pragma unroll
+    for (int k = 0; k < TJ / kBlock; ++k) {
+        const uint32_t j = j0 + (uint32_t)(k * kBlock + tid);
+        t.r[k] = (j < jend) ? pos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int TJ>
+__device__ __forceinline__ void tile_store(const TileRegs<TJ> &t, float4 *lds_tile, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < TJ / kBlock; ++k) lds_tile[k * kBlock + tid] = t.r[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// STRICT arithmetic
+// ------------------------------------------------------------------------------------------------
+
+// 1 if a coordinate lies outside {0} U [lo, hi] in magnitude (NaN/inf included): then the unscaled
+// division ladder is not guaranteed exact and the tile takes the IEEE '/' path.
+__device__ __forceinline__ uint32_t coord_oor(float c, uint32_t lo_bits, uint32_t span_bits)
+{
+    const uint32_t u = __float_as_uint(c) & 0x7fffffffu;
+    return (uint32_t)((u != 0u) & ((u - lo_bits) > span_bits));
+}
+
+// Three correctly rounded quotients n{x,y,z} / d with ONE reciprocal.
+// This is exactly the ladder LLVM's AMDGPU backend emits for an IEEE binary32 divide
+//   r0 = rcp(d); e = fma(-d,r0,1); r = fma(e,r0,r0);
+//   q0 = n*r; t0 = fma(-d,q0,n); q1 = fma(t0,r,q0); t1 = fma(-d,q1,n); q = fma(t1,r,q1)
+// minus v_div_scale / v_div_fmas scaling / v_div_fixup, which are the identity when d, n and n/d are
+// normal with headroom -- what coord_oor() + the parameter check in nb_api guarantee.  The reciprocal
+// refinement depends on d only, so the three components share it (11 fewer VALU ops per pair).
+__device__ __forceinline__ float div_ladder(float n, float d, float r)
+{
+    const float q0 = n * r;
+    const float t0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(t0, r, q0);
+    const float t1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(t1, r, q1);
+}
+
+template <bool IEEE>
+__device__ __forceinline__ void pair_strict(const float4 pj, float xi, float yi, float zi, float G, float bias, float &qx,
+                                            float &qy, float &qz)
+{
+    // main.rs:428  vec = p_i - p_n   (the reference recomputes the same difference inside distance2)
+    const float dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi;
+    // main.rs:429  dist = ((dx*dx + dy*dy) + dz*dz) + bias
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float d = ((xx + yy) + zz) + bias;
+    // main.rs:430  (vec * G) / dist, component-wise
+    const float nx = dx * G, ny = dy * G, nz = dz * G;
+    if (IEEE) {
+        qx = nx / d;
+        qy = ny / d;
+        qz = nz / d;
+    } else {
+        const float r0 = __builtin_amdgcn_rcpf(d);
+        const float e = __builtin_fmaf(-d, r0, 1.0f);
+        const float r = __builtin_fmaf(e, r0, r0);
+        qx = div_ladder(nx, d, r);
+        qy = div_ladder(ny, d, r);
+        qz = div_ladder(nz, d, r);
+    }
+}
+
+template <bool IEEE, int U>
+__device__ __forceinline__ void fold_tile_strict(const float4 *tile, int nj, float xi, float yi, float zi, float G,
+                                                 float bias, float &sx, float &sy, float &sz)
+{
+    int j = 0;
+    for (; j + U <= nj; j += U) {
+        float qx[U], qy[U], qz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pair_strict<IEEE>(tile[j + u], xi, yi, zi, G, bias, qx[u], qy[u], qz[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // main.rs:430  sum + term, strictly in index order
+            sx = sx + qx[u];
+            sy = sy + qy[u];
+            sz = sz + qz[u];
+        }
+    }
+    for (; j < nj; ++j) {
+        float qx, qy, qz;
+        pair_strict<IEEE>(tile[j], xi, yi, zi, G, bias, qx, qy, qz);
+        sx = sx + qx;
+        sy = sy + qy;
+        sz = sz + qz;
+    }
+}
+
+// main.rs:434, 436 -- shared by both modes; unfused on purpose (two roundings each).
+__device__ __forceinline__ void integrate(float4 &p, float4 &v, float ax, float ay, float az, float dt)
+{
+    const float ex = ax * dt, ey = ay * dt, ez = az * dt;
+    v.x = v.x + ex;
+    v.y = v.y + ey;
+    v.z = v.z + ez;
+    p.x = v.x + p.x;
+    p.y = v.y + p.y;
+    p.z = v.z + p.z;
+    p.w = 0.f;
+    v.w = 0.f;
+}
+
+template <int TJ>
+__global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
+{
+    __shared__ float4 tile[2][TJ];
+    __shared__ uint32_t tile_bad[2][kWaves];
+    __shared__ uint32_t self_bad[kWaves];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + (uint32_t)tid;  // index inside the shard
+    const bool live = l < a.count;
+    const uint32_t gi = a.first + (live ? l : a.count - 1u);
+    const float4 pi = a.pos_in[gi];
+    const float xi = pi.x, yi = pi.y, zi = pi.z;
+
+    const uint32_t lo = a.lo_bits, span = a.hi_bits - a.lo_bits;
+    {
+        const uint32_t bad = coord_oor(xi, lo, span) | coord_oor(yi, lo, span) | coord_oor(zi, lo, span) | a.force_ieee;
+        const uint32_t wbad = __any((int)bad) ? 1u : 0u;
+        if ((tid & 63) == 0) self_bad[wave] = wbad;
+    }
+
+    TileRegs<TJ> regs;
+    const uint32_t n = a.n_total;
+    const uint32_t ntiles = (n + (uint32_t)TJ - 1u) / (uint32_t)TJ;
+    tile_fetch<TJ>(regs, a.pos_in, 0u, n, tid);
+    auto publish = [&](int buf) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int k = 0; k < TJ / kBlock; ++k)
+            bad |= coord_oor(regs.r[k].x, lo, span) | coord_oor(regs.r[k].y, lo, span) | coord_oor(regs.r[k].z, lo, span);
+        const uint32_t wbad = __any((int)bad) ? 1u : 0u;
+        tile_store<TJ>(regs, tile[buf], tid);
+        if ((tid & 63) == 0) tile_bad[buf][wave] = wbad;
+    };
+    publish(0);
+    __syncthreads();
+    const uint32_t block_self_bad = self_bad[0] | self_bad[1] | self_bad[2] | self_bad[3];
+
+    float sx = 0.f, sy = 0.f, sz = 0.f;  // main.rs:426  Vector3::new(0.0, 0.0, 0.0)
+    int buf = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1u) < ntiles;
+        if (more) tile_fetch<TJ>(regs, a.pos_in, (t + 1u) * (uint32_t)TJ, n, tid);
+        const uint32_t ieee = block_self_bad | tile_bad[buf][0] | tile_bad[buf][1] | tile_bad[buf][2] | tile_bad[buf][3];
+        const uint32_t left = n - t * (uint32_t)TJ;
+        const int nj = left < (uint32_t)TJ ? (int)left : TJ;
+        if (ieee == 0u)
+            fold_tile_strict<false, 4>(tile[buf], nj, xi, yi, zi, a.G, a.bias, sx, sy, sz);
+        else
+            fold_tile_strict<true, 2>(tile[buf], nj, xi, yi, zi, a.G, a.bias, sx, sy, sz);
+        if (more) publish(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (live) {
+        float4 p = pi;
+        float4 v = a.vel[l];
+        integrate(p, v, sx, sy, sz, a.dt);
+        a.vel[l] = v;
+        a.pos_out[a.first + l] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST arithmetic
+// ------------------------------------------------------------------------------------------------
+template <int IB, int U>
+__device__ __forceinline__ void fold_tile_fast(const float4 *tile, int nj, const float (&xi)[IB], const float (&yi)[IB],
+                                               const float (&zi)[IB], float bias, float (&ax)[IB], float (&ay)[IB],
+                                               float (&az)[IB])
+{
+    auto pair = [&](const float4 pj) {
+#pragma unroll
+        for (int b = 0; b < IB; ++b) {
+            const float dx = pj.x - xi[b], dy = pj.y - yi[b], dz = pj.z - zi[b];
+            float r2 = __builtin_fmaf(dx, dx, bias);
+            r2 = __builtin_fmaf(dy, dy, r2);
+            r2 = __builtin_fmaf(dz, dz, r2);
+            const float inv = __builtin_amdgcn_rcpf(r2);
+            ax[b] = __builtin_fmaf(dx, inv, ax[b]);
+            ay[b] = __builtin_fmaf(dy, inv, ay[b]);
+            az[b] = __builtin_fmaf(dz, inv, az[b]);
+        }
+    };
+    int j = 0;
+    for (; j + U <= nj; j += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) pair(tile[j + u]);
+    }
+    for (; j < nj; ++j) pair(tile[j]);
+}
+
+// grid.x: blocks of 256*IB bodies; grid.y: slices of the j range (a.j_chunk records each, a multiple of TJ).
+// gridDim.y == 1: fused integrate epilogue.  Otherwise partial sums go to a.partial[jy][count] and
+// integrate_partials_kernel combines them in slice order.
+template <int TJ, int IB>
+__global__ __launch_bounds__(kBlock) void step_fast_kernel(StepArgs a)
+{
+    __shared__ float4 tile[2][TJ];
+
+    const int tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)(kBlock * IB) + (uint32_t)tid;
+    float xi[IB], yi[IB], zi[IB], ax[IB], ay[IB], az[IB];
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+        const uint32_t l = base + (uint32_t)(b * kBlock);
+        const float4 p = a.pos_in[a.first + (l < a.count ? l : a.count - 1u)];
+        xi[b] = p.x;
+        yi[b] = p.y;
+        zi[b] = p.z;
+        ax[b] = ay[b] = az[b] = 0.f;
+    }
+
+    const uint32_t j_lo = blockIdx.y * a.j_chunk;
+    const uint32_t j_hi = (j_lo + a.j_chunk < a.n_total) ? j_lo + a.j_chunk : a.n_total;
+    const uint32_t span = j_hi > j_lo ? j_hi - j_lo : 0u;
+    const uint32_t ntiles = (span + (uint32_t)TJ - 1u) / (uint32_t)TJ;
+
+    TileRegs<TJ> regs;
+    if (ntiles) {
+        tile_fetch<TJ>(regs, a.pos_in, j_lo, j_hi, tid);
+        tile_store<TJ>(regs, tile[0], tid);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1u) < ntiles;
+        if (more) tile_fetch<TJ>(regs, a.pos_in, j_lo + (t + 1u) * (uint32_t)TJ, j_hi, tid);
+        const uint32_t left = span - t * (uint32_t)TJ;
+        const int nj = left < (uint32_t)TJ ? (int)left : TJ;
+        fold_tile_fast<IB, 8 / IB>(tile[buf], nj, xi, yi, zi, a.bias, ax, ay, az);
+        if (more) tile_store<TJ>(regs, tile[buf ^ 1], tid);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int b = 0; b < IB; ++b) {
+        const uint32_t l = base + (uint32_t)(b * kBlock);
+        if (l >= a.count) continue;
+        if (gridDim.y == 1) {
+            float4 p = make_float4(xi[b], yi[b], zi[b], 0.f);
+            float4 v = a.vel[l];
+            integrate(p, v, ax[b] * a.G, ay[b] * a.G, az[b] * a.G, a.dt);
+            a.vel[l] = v;
+            a.pos_out[a.first + l] = p;
+        } else {
+            a.partial[(size_t)blockIdx.y * a.count + l] = make_float4(ax[b], ay[b], az[b], 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void integrate_partials_kernel(StepArgs a, uint32_t slices)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= a.count) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (uint32_t s = 0; s < slices; ++s) {  // fixed order: deterministic
+        const float4 q = a.partial[(size_t)s * a.count + l];
+        sx = sx + q.x;
+        sy = sy + q.y;
+        sz = sz + q.z;
+    }
+    float4 p = a.pos_in[a.first + l];
+    float4 v = a.vel[l];
+    integrate(p, v, sx * a.G, sy * a.G, sz * a.G, a.dt);
+    a.vel[l] = v;
+    a.pos_out[a.first + l] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model matrices, main.rs:437-439:  M = from_translation(p) * from_angle_z(atan2(v.y, v.x)), evaluated as
+// the explicit column-by-column product cgmath performs (so signed zeros and non-finite positions come
+// out the way they do in the reference).  atan2f/sinf/cosf are the device libm's: within a few ulp of
+// the host libm the reference uses; tests hold them to 1e-6 absolute.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void instances_kernel(uint32_t count, const float4 *__restrict__ pos,
+                                                           const float4 *__restrict__ vel, float4 *__restrict__ inst)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= count) return;
+    const float4 p = pos[l];
+    const float4 v = vel[l];
+    const float theta = atan2f(v.y, v.x);
+    const float s = sinf(theta);
+    const float c = cosf(theta);
+    const float A[4] = {1.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 1.f, 0.f, 0.f}, C[4] = {0.f, 0.f, 1.f, 0.f};
+    const float D[4] = {p.x, p.y, p.z, 1.f};
+    const float R[4][4] = {{c, s, 0.f, 0.f}, {-s, c, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f}, {0.f, 0.f, 0.f, 1.f}};
+    float m[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t0 = A[e] * R[k][0], t1 = B[e] * R[k][1], t2 = C[e] * R[k][2], t3 = D[e] * R[k][3];
+            m[4 * k + e] = ((t0 + t1) + t2) + t3;
+        }
+    float4 *out = inst + (size_t)l * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+}
+
+// stride-3 host layout <-> 16-byte device records
+__global__ __launch_bounds__(kBlock) void pack_kernel(uint32_t count, const float *__restrict__ xyz, float4 *__restrict__ rec)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= count) return;
+    rec[l] = make_float4(xyz[3 * (size_t)l], xyz[3 * (size_t)l + 1], xyz[3 * (size_t)l + 2], 0.f);
+}
+
+__global__ __launch_bounds__(kBlock) void unpack_kernel(uint32_t count, const float4 *__restrict__ rec, float *__restrict__ xyz)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= count) return;
+    const float4 r = rec[l];
+    xyz[3 * (size_t)l] = r.x;
+    xyz[3 * (size_t)l + 1] = r.y;
+    xyz[3 * (size_t)l + 2] = r.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+template <int TJ>
+static hipError_t launch_strict_t(const StepArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(step_strict_kernel<TJ>, dim3(ceil_div(a.count, kBlock)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, hipStream_t s)
+{
+    switch (tile) {
+        case 256: return launch_strict_t<256>(a, s);
+        case 512: return launch_strict_t<512>(a, s);
+        case 1024: return launch_strict_t<1024>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int TJ, int IB>
+static hipError_t launch_fast_t(const StepArgs &a, uint32_t slices, hipStream_t s)
+{
+    hipLaunchKernelGGL((step_fast_kernel<TJ, IB>), dim3(ceil_div(a.count, kBlock * IB), slices), dim3(kBlock), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || slices == 1) return e;
+    hipLaunchKernelGGL(integrate_partials_kernel, dim3(ceil_div(a.count, kBlock)), dim3(kBlock), 0, s, a, slices);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s)
+{
+#define NBK_CASE(T, I) \
+    if (tile == T && ib == I) return launch_fast_t<T, I>(a, slices, s)
+    NBK_CASE(256, 1);
+    NBK_CASE(256, 2);
+    NBK_CASE(256, 4);
+    NBK_CASE(512, 1);
+    NBK_CASE(512, 2);
+    NBK_CASE(512, 4);
+    NBK_CASE(1024, 1);
+    NBK_CASE(1024, 2);
+    NBK_CASE(1024, 4);
+#undef NBK_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s)
+{
+    hipLaunchKernelGGL(instances_kernel, dim3(ceil_div(count, kBlock)), dim3(kBlock), 0, s, count, pos, vel, inst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_kernel, dim3(ceil_div(count, kBlock)), dim3(kBlock), 0, s, count, xyz, rec);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s)
+{
+    hipLaunchKernelGGL(unpack_kernel, dim3(ceil_div(count, kBlock)), dim3(kBlock), 0, s, count, rec, xyz);
+    return hipGetLastError();
+}
+
+}  // namespace nbk

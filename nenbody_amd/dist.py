@@ -1,0 +1,166 @@
+"""Body set sharded over one process per GPU, one all-gather of positions per step.
+
+Within a step every body depends only on the start-of-step snapshot of ALL positions
+(``old_positions``, src/main.rs:415, 425), so the set shards by contiguous index range with exactly one
+exchange: after the local update each rank contributes its new positions and receives everyone else's
+(RCCL all-gather over xGMI; ``torch.distributed`` backend "nccl" is RCCL on ROCm).  Velocities never move.
+STRICT results do not depend on the world size: a body's fold order over j is unchanged by sharding.
+
+torch is plumbing here: device buffers, the stream, the collective.  The step itself is
+``nb_launch_step`` (include/nenbody.h) on the raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import NbParams, check
+
+__all__ = ["partition", "ShardedScene", "HipBackend"]
+
+
+def partition(n: int, world: int) -> List[Tuple[int, int]]:
+    """(first, count) of every rank: equal slots of ceil(n/world) bodies; trailing slots may be short or empty.
+
+    Equal slots keep the all-gather a plain (non-v) collective: the position buffer holds
+    ``world * slot`` records, of which the kernel only ever reads the first n.
+    """
+    if n <= 0 or world <= 0:
+        raise ValueError("partition needs n > 0 and world > 0")
+    slot = -(-n // world)
+    out = []
+    for r in range(world):
+        first = min(r * slot, n)
+        out.append((first, max(0, min(n - first, slot))))
+    return out
+
+
+class HipBackend:
+    """The product compute backend: libnenbody_hip.so's launch API on torch-owned device memory."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def scratch_bytes(self, params: NbParams, n_total: int, count: int) -> int:
+        return int(self.lib.nb_scratch_bytes(ctypes.byref(params), n_total, count))
+
+    def step(self, params, n_total, first, count, pos_in, pos_out, vel, scratch) -> None:
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        sp = scratch.data_ptr() if scratch is not None and scratch.numel() else None
+        sb = scratch.numel() if scratch is not None else 0
+        check(self.lib.nb_launch_step(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
+                                      vel.data_ptr(), sp, sb, stream))
+
+    def instances(self, count, pos, vel, inst) -> None:
+        import torch
+
+        stream = torch.cuda.current_stream(pos.device).cuda_stream
+        check(self.lib.nb_launch_instances(count, pos.data_ptr(), vel.data_ptr(), inst.data_ptr(), stream))
+
+
+class ShardedScene:
+    """One rank's share of a Scene: bodies [first, first+count) plus a replica of all positions.
+
+    ``positions`` / ``velocities`` are the FULL (n, 3) host arrays, identical on every rank (each rank keeps
+    its own slice of the velocities).  ``group`` is a torch.distributed process group (None = default group;
+    a world of 1 needs no initialised process group at all).
+    """
+
+    def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, device=None, group=None,
+                 backend=None, rank: Optional[int] = None, world: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch = torch
+        self.dist = dist
+        self.group = group
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if world > 1 else 0
+        self.world, self.rank = world, rank
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        vel = np.ascontiguousarray(velocities, dtype=np.float32)
+        if pos.ndim != 2 or pos.shape[1] != 3 or pos.shape != vel.shape:
+            raise ValueError("positions and velocities must both have shape (n, 3)")
+        self.n = len(pos)
+        self.params = params if params is not None else _lib.default_params()
+        self.backend = backend if backend is not None else HipBackend()
+        if device is None:
+            if self.backend.name == "hip":
+                if not torch.cuda.is_available():
+                    raise _lib.NbError(_lib.NB_ERR_NO_DEVICE, "no HIP device visible to torch; nenbody_amd has no CPU path")
+                device = torch.device("cuda", torch.cuda.current_device())
+            else:
+                device = torch.device("cpu")
+        self.device = torch.device(device)
+        parts = partition(self.n, world)
+        self.first, self.count = parts[rank]
+        self.slot = -(-self.n // world)
+        padded = self.slot * world
+        rec = torch.zeros((padded, 4), dtype=torch.float32)
+        rec[: self.n, :3] = torch.from_numpy(pos)
+        self.pos = [rec.to(self.device), torch.zeros((padded, 4), dtype=torch.float32, device=self.device)]
+        vrec = torch.zeros((max(self.count, 1), 4), dtype=torch.float32)
+        if self.count:
+            vrec[: self.count, :3] = torch.from_numpy(vel[self.first:self.first + self.count])
+        self.vel = vrec.to(self.device)
+        sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
+        self.scratch = torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None
+        self.cur = 0
+        self.steps_done = 0
+
+    # -- one step: local update, then the exchange ------------------------------------------------------
+    def step(self) -> None:
+        src, dst = self.pos[self.cur], self.pos[self.cur ^ 1]
+        if self.count:
+            self.backend.step(self.params, self.n, self.first, self.count, src, dst, self.vel, self.scratch)
+        if self.world > 1:
+            lo = self.rank * self.slot
+            mine = dst[lo:lo + self.slot]
+            if self.dist.get_backend(self.group) != "nccl":
+                mine = mine.clone()  # in-place (aliased) all-gather is an NCCL/RCCL convention
+            self.dist.all_gather_into_tensor(dst, mine, group=self.group)
+        self.cur ^= 1
+        self.steps_done += 1
+
+    def step_n(self, k: int) -> None:
+        for _ in range(int(k)):
+            self.step()
+
+    def sync(self) -> None:
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
+
+    # -- state access -------------------------------------------------------------------------------------
+    def positions(self) -> np.ndarray:
+        """All n positions (every rank holds the replica), shape (n, 3)."""
+        return self.pos[self.cur][: self.n, :3].cpu().numpy().copy()
+
+    def local_velocities(self) -> np.ndarray:
+        return self.vel[: self.count, :3].cpu().numpy().copy()
+
+    def velocities(self) -> np.ndarray:
+        """All n velocities, gathered on demand (not part of the per-step exchange)."""
+        if self.world == 1:
+            return self.local_velocities()
+        slot_v = self.torch.zeros((self.slot, 4), dtype=self.torch.float32, device=self.device)
+        slot_v[: self.count] = self.vel[: self.count]
+        full = self.torch.zeros((self.slot * self.world, 4), dtype=self.torch.float32, device=self.device)
+        self.dist.all_gather_into_tensor(full, slot_v, group=self.group)
+        return full[: self.n, :3].cpu().numpy().copy()
+
+    def local_instances(self) -> np.ndarray:
+        """Model matrices (main.rs:437-439) of this rank's bodies, shape (count, 4, 4)."""
+        inst = self.torch.zeros((max(self.count, 1), 16), dtype=self.torch.float32, device=self.device)
+        if self.count:
+            mine = self.pos[self.cur][self.first:self.first + self.count]
+            self.backend.instances(self.count, mine, self.vel, inst)
+        return inst[: self.count].cpu().numpy().reshape(self.count, 4, 4).copy()

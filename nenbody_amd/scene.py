@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's update interface for the n-body path, over the C ABI.
+
+The reference keeps the simulation state in ``main()`` (``positions``, ``velocities``, ``old_positions``,
+``old_velocities``, ``instance_data``: src/main.rs:738-750) and advances it with the free function
+``update_instance_nbody`` (src/main.rs:404-441), called once per redraw (call-site shape: src/main.rs:925-931).
+Its ``src/scene.rs`` is empty (src/scene.rs:1); :class:`Scene` is the type that module was evidently meant
+to hold, and :func:`update_instance_nbody` keeps the reference's own five-argument signature.
+
+Everything here is plumbing (numpy arrays in, ctypes calls, numpy arrays out).  The arithmetic runs in
+libnenbody_hip.so on the GPU; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import NB_MODE_FAST, NB_MODE_STRICT, NbError, NbParams, check  # noqa: F401  (re-exported)
+
+__all__ = ["Scene", "update_instance_nbody", "init_state", "NB_MODE_STRICT", "NB_MODE_FAST", "NbParams", "NbError"]
+
+
+def _as_f32(a, shape_tail, name):
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if arr.ndim != len(shape_tail) + 1 or tuple(arr.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} must have shape (n, {', '.join(map(str, shape_tail))}), got {arr.shape}")
+    return arr
+
+
+def init_state(n: int, seed: int = 1234):
+    """Seeded stand-in for the reference's unseeded initial state (src/main.rs:736-747).
+
+    Returns (positions, velocities), float32 arrays of shape (n, 3): velocities (U[0,0.1), U[0,0.1), 0)
+    drawn first for every body, then positions (U[-100,100), U[-100,100), 0) -- the reference's
+    distributions and draw order.
+    """
+    pos = np.empty((n, 3), np.float32)
+    vel = np.empty((n, 3), np.float32)
+    check(_lib.load().nb_init_state(seed, n, pos.ctypes.data, vel.ctypes.data))
+    return pos, vel
+
+
+class Scene:
+    """Device-resident n-body state with the update of src/main.rs:404-441 as :meth:`step`.
+
+    Host mirrors (``positions``, ``velocities``, ``instances``) are refreshed by :meth:`step`, so the
+    consumers at src/main.rs:932-945 (instance upload, cameras) would read them unchanged;
+    :meth:`step_n` keeps everything on the device and is the benchmark path.
+    """
+
+    def __init__(self, positions, velocities, params: Optional[NbParams] = None):
+        lib = _lib.load()
+        pos = _as_f32(positions, (3,), "positions")
+        vel = _as_f32(velocities, (3,), "velocities")
+        if len(pos) != len(vel):
+            raise ValueError("positions and velocities must have the same length")
+        if len(pos) == 0:
+            raise ValueError("a Scene needs at least one body")
+        self.n = len(pos)
+        self.params = params if params is not None else _lib.default_params()
+        self._lib = lib
+        self._ctx = ctypes.c_void_p()
+        check(lib.nb_create(self.n, 1, ctypes.byref(self.params), ctypes.byref(self._ctx)))
+        self._positions = pos.copy()
+        self._velocities = vel.copy()
+        self._instances = np.zeros((self.n, 4, 4), np.float32)
+        try:
+            check(lib.nb_upload(self._ctx, self._positions.ctypes.data, self._velocities.ctypes.data), self._ctx)
+        except Exception:
+            self.close()
+            raise
+
+    # -- constructors mirroring the Rust shim ---------------------------------------
+    @classmethod
+    def new(cls, n: int, params: Optional[NbParams] = None, seed: int = 1234) -> "Scene":
+        pos, vel = init_state(n, seed)
+        return cls(pos, vel, params)
+
+    @classmethod
+    def from_state(cls, positions, velocities, params: Optional[NbParams] = None) -> "Scene":
+        return cls(positions, velocities, params)
+
+    # -- stepping ---------------------------------------------------------------------------------------
+    def step(self) -> None:
+        """One update_instance_nbody, then refresh the host mirrors (positions, velocities, instances)."""
+        check(self._lib.nb_step(self._ctx, 1), self._ctx)
+        self._refresh(True)
+
+    def step_n(self, k: int) -> None:
+        """k updates, device-resident and asynchronous; host mirrors are NOT refreshed (see :meth:`sync`)."""
+        check(self._lib.nb_step(self._ctx, int(k)), self._ctx)
+
+    def sync(self) -> None:
+        check(self._lib.nb_sync(self._ctx), self._ctx)
+
+    @property
+    def steps_done(self) -> int:
+        return int(self._lib.nb_steps_done(self._ctx))
+
+    # -- state access -----------------------------------------------------------------------------------
+    def _refresh(self, with_instances: bool) -> None:
+        inst = self._instances.ctypes.data if with_instances else None
+        check(self._lib.nb_download(self._ctx, self._positions.ctypes.data, self._velocities.ctypes.data, inst), self._ctx)
+
+    def positions(self) -> np.ndarray:
+        self._refresh(False)
+        return self._positions
+
+    def velocities(self) -> np.ndarray:
+        self._refresh(False)
+        return self._velocities
+
+    def instances(self) -> np.ndarray:
+        """Model matrices of the current state, shape (n, 4, 4); [k] is column k (column-major, main.rs:437-439)."""
+        self._refresh(True)
+        return self._instances
+
+    def state(self):
+        self._refresh(False)
+        return self._positions.copy(), self._velocities.copy()
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.nb_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def update_instance_nbody(instances, positions, old_positions, velocities, old_velocities,
+                          params: Optional[NbParams] = None) -> None:
+    """The reference's operator, same five arguments, updated in place (src/main.rs:404-410).
+
+    ``instances`` is (n, 4, 4) float32, the others (n, 3) float32 numpy arrays (they must be writable,
+    C-contiguous float32: they are the caller's ``Vec``s).  Behaviour kept from the reference:
+      * ``old_positions`` / ``old_velocities`` receive copies of the inputs (main.rs:415-416); a length
+        mismatch is an error, as ``copy_from_slice`` panics;
+      * ``instances.zip(positions).zip(velocities)`` stops at the shortest of the three (main.rs:420-423):
+        only that many bodies are updated, while the fold still runs over all of ``old_positions``.
+    One upload, one step, one download per call: this is the drop-in form, not the fast one -- a caller
+    that steps repeatedly should hold a :class:`Scene`.
+    """
+    for name, arr, tail in (("instances", instances, (4, 4)), ("positions", positions, (3,)),
+                            ("old_positions", old_positions, (3,)), ("velocities", velocities, (3,)),
+                            ("old_velocities", old_velocities, (3,))):
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.flags.c_contiguous and arr.flags.writeable):
+            raise TypeError(f"{name} must be a writable C-contiguous float32 numpy array")
+        if arr.ndim != len(tail) + 1 or tuple(arr.shape[1:]) != tail:
+            raise ValueError(f"{name} must have shape (n, {', '.join(map(str, tail))})")
+    if len(old_positions) != len(positions):
+        raise ValueError("source slice length does not match destination slice length (old_positions vs positions)")
+    if len(old_velocities) != len(velocities):
+        raise ValueError("source slice length does not match destination slice length (old_velocities vs velocities)")
+    old_positions[...] = positions  # main.rs:415
+    old_velocities[...] = velocities  # main.rs:416
+    count = min(len(instances), len(positions), len(velocities))  # zip semantics, main.rs:420-423
+    if count == 0:
+        return
+    n = len(positions)
+    vel_full = velocities
+    if len(velocities) < n:  # bodies past the zip are computed and discarded; give them a velocity to carry
+        vel_full = np.zeros((n, 3), np.float32)
+        vel_full[: len(velocities)] = velocities
+    with Scene(old_positions, vel_full[:n], params) as sc:
+        sc.step()
+        positions[:count] = sc._positions[:count]
+        velocities[:count] = sc._velocities[:count]
+        instances[:count] = sc._instances[:count]

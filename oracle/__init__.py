@@ -1,0 +1,104 @@
+"""ctypes wrapper of the CPU oracle (oracle/nbody_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+nenbody_amd never imports this package.  Parity of the oracle itself is UNPINNED by the reference (it ships no
+tests and cannot be built here); see the header of nbody_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbody_oracle.so")
+
+# reference constants, src/main.rs:411-413
+DT, G, BIAS = np.float32(0.1), np.float32(0.001), np.float32(0.0000001)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "nbody_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libnbody_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, u32, u64, f, i = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
+        lib.nbo_init_state.argtypes = [u64, u32, vp, vp]
+        lib.nbo_init_state.restype = None
+        lib.nbo_instances.argtypes = [vp, vp, vp, u32]
+        lib.nbo_instances.restype = None
+        lib.nbo_step_range.argtypes = [vp, vp, vp, vp, u32, u32, u32, f, f, f]
+        lib.nbo_step_range.restype = None
+        lib.nbo_run.argtypes = [vp, vp, vp, u32, u32, f, f, f, i]
+        lib.nbo_run.restype = i
+        lib.nbo_run_f64.argtypes = [vp, vp, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        lib.nbo_run_f64.restype = i
+        _lib = lib
+    return _lib
+
+
+def ncores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def init_state(n: int, seed: int = 1234):
+    pos = np.empty((n, 3), np.float32)
+    vel = np.empty((n, 3), np.float32)
+    load().nbo_init_state(seed, n, pos.ctypes.data, vel.ctypes.data)
+    return pos, vel
+
+
+def run(pos, vel, k: int, dt=DT, g=G, bias=BIAS, threads: int = 0, want_instances: bool = False):
+    """k applications of update_instance_nbody (main.rs:404-441).  Returns new (pos, vel[, instances])."""
+    p = np.ascontiguousarray(pos, np.float32).copy()
+    v = np.ascontiguousarray(vel, np.float32).copy()
+    n = len(p)
+    inst = np.zeros((n, 4, 4), np.float32) if want_instances else None
+    rc = load().nbo_run(p.ctypes.data, v.ctypes.data, inst.ctypes.data if want_instances else None, n, k, dt, g, bias,
+                        threads or ncores())
+    assert rc == 0
+    return (p, v, inst) if want_instances else (p, v)
+
+
+def step_range(old_pos, vel_range, first: int, count: int, dt=DT, g=G, bias=BIAS, want_instances: bool = False):
+    """One step for bodies [first, first+count) against the snapshot of all positions (one thread)."""
+    old = np.ascontiguousarray(old_pos, np.float32)
+    v = np.ascontiguousarray(vel_range, np.float32).copy()
+    assert len(v) == count
+    p = np.empty((count, 3), np.float32)
+    inst = np.zeros((count, 4, 4), np.float32) if want_instances else None
+    load().nbo_step_range(old.ctypes.data, p.ctypes.data, v.ctypes.data, inst.ctypes.data if want_instances else None,
+                          len(old), first, count, dt, g, bias)
+    return (p, v, inst) if want_instances else (p, v)
+
+
+def instances(pos, vel):
+    p = np.ascontiguousarray(pos, np.float32)
+    v = np.ascontiguousarray(vel, np.float32)
+    inst = np.zeros((len(p), 4, 4), np.float32)
+    load().nbo_instances(p.ctypes.data, v.ctypes.data, inst.ctypes.data, len(p))
+    return inst
+
+
+def run_f64(pos, vel, k: int, dt=0.1, g=0.001, bias=0.0000001):
+    p = np.ascontiguousarray(pos, np.float64).copy()
+    v = np.ascontiguousarray(vel, np.float64).copy()
+    rc = load().nbo_run_f64(p.ctypes.data, v.ctypes.data, len(p), k, dt, g, bias)
+    assert rc == 0
+    return p, v

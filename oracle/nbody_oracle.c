@@ -1,0 +1,280 @@
+/*
+ * nbody_oracle.c -- CPU restatement of nenbody's all-pairs gravity + Euler step.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The shipped
+ * library (nenbody_amd/lib/libnenbody_hip.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference (Rust) cannot be compiled in this environment
+ * (no cargo/rustc) and ships no tests, golden vectors or fixtures for this path
+ * (SURVEY.md section 4 / 8c).  This file restates src/main.rs:404-441 operation by
+ * operation; it is cross-checked by an independent numpy float32 restatement and by
+ * hand-derived known-answer tests (tests/test_oracle.py), nothing stronger.
+ *
+ * The arithmetic lives in the third-party crate cgmath 0.17.0 (Cargo.toml:16,
+ * Cargo.lock:177-185), which is not vendored under /root/reference.  Its published
+ * semantics, as used at the reference's call sites:
+ *   Point3 - Point3, Vector3 +/- Vector3    component-wise
+ *   Vector3 * f32, Vector3 / f32            component-wise (a true IEEE divide per component)
+ *   MetricSpace::distance2(self, other)     (other - self).magnitude2() = dot(d, d)
+ *   dot(a, b) for Vector3                   (a.x*b.x + a.y*b.y) + a.z*b.z   (sum of products, left to right)
+ *   Matrix4::from_translation(v)            identity with column 3 = (v.x, v.y, v.z, 1)
+ *   Matrix4::from_angle_z(t)                (s, c) = sin_cos(t); columns (c,s,0,0), (-s,c,0,0), (0,0,1,0), (0,0,0,1)
+ *   Matrix4 * Matrix4                       column k = ((a*r[k][0] + b*r[k][1]) + c*r[k][2]) + d*r[k][3],
+ *                                           a..d = columns of lhs, Vector4 ops component-wise
+ *   Angle::atan2(y, x)                      Rad(y.atan2(x)) -> libm atan2f
+ * rustc/LLVM neither contracts a*b+c into an FMA nor reassociates float adds without
+ * fast-math, so this file MUST be built with -ffp-contract=off and without
+ * -ffast-math (see oracle/Makefile).  All arithmetic is IEEE binary32.
+ *
+ * Memory layout at this boundary: positions and velocities are AoS stride-3 float
+ * arrays (x,y,z), i.e. the in-memory form of Vec<Point3<f32>> / Vec<Vector3<f32>>;
+ * instance matrices are 16 floats per body, column-major ([[f32;4];4]).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NBO_API __attribute__((visibility("default")))
+
+/* src/main.rs:411-413 */
+#define NBO_DT 0.1f
+#define NBO_G 0.001f
+#define NBO_BIAS 0.0000001f
+
+NBO_API int nbo_abi_version(void) { return 1; }
+
+NBO_API void nbo_default_constants(float *dt, float *G, float *bias)
+{
+    *dt = NBO_DT;
+    *G = NBO_G;
+    *bias = NBO_BIAS;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Seeded initial conditions.  The reference draws from rand::thread_rng(), which is
+ * unseeded and cannot be reproduced (src/main.rs:737).  This generator is build-owned;
+ * it keeps the reference's DISTRIBUTIONS and DRAW ORDER (src/main.rs:738-747):
+ *   first, for every body: velocity = (U[0,0.1), U[0,0.1), 0)
+ *   then,  for every body: position = (U[-100,100), U[-100,100), 0)
+ * Bit source: splitmix64; uniform: 24 high bits -> u in [0,1), value = lo + (hi-lo)*u in
+ * binary32 (one multiply, one add).  nenbody_amd's nb_init_state must produce the same bits.
+ * ---------------------------------------------------------------------------------- */
+static uint64_t splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static float uniform_f32(uint64_t *s, float lo, float hi)
+{
+    uint32_t bits24 = (uint32_t)(splitmix64(s) >> 40);
+    float u = (float)bits24 * 0x1.0p-24f;
+    float scale = hi - lo;
+    float v = scale * u;
+    return lo + v;
+}
+
+NBO_API void nbo_init_state(uint64_t seed, uint32_t n, float *pos3, float *vel3)
+{
+    uint64_t s = seed;
+    for (uint32_t i = 0; i < n; ++i) { /* src/main.rs:738-742 */
+        vel3[3 * i + 0] = uniform_f32(&s, -0.0f, 0.1f);
+        vel3[3 * i + 1] = uniform_f32(&s, -0.0f, 0.1f);
+        vel3[3 * i + 2] = 0.0f;
+    }
+    for (uint32_t i = 0; i < n; ++i) { /* src/main.rs:743-747 */
+        pos3[3 * i + 0] = uniform_f32(&s, -100.0f, 100.0f);
+        pos3[3 * i + 1] = uniform_f32(&s, -100.0f, 100.0f);
+        pos3[3 * i + 2] = 0.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Instance matrix (src/main.rs:437-439, rotation_of src/main.rs:141-143).
+ * ---------------------------------------------------------------------------------- */
+static void vec4_scale(float out[4], const float v[4], float s)
+{
+    for (int k = 0; k < 4; ++k) out[k] = v[k] * s;
+}
+
+static void instance_matrix(float m[16], const float p[3], const float v[3])
+{
+    float theta = atan2f(v[1], v[0]); /* main.rs:142: cgmath::Angle::atan2(v.y, v.x) */
+    float s = sinf(theta);            /* f32::sin_cos = (sin, cos) */
+    float c = cosf(theta);
+    /* lhs = from_translation(p): columns a,b,c,d */
+    const float a[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    const float b[4] = {0.0f, 1.0f, 0.0f, 0.0f};
+    const float cc[4] = {0.0f, 0.0f, 1.0f, 0.0f};
+    const float d[4] = {p[0], p[1], p[2], 1.0f};
+    /* rhs = from_angle_z(theta): columns */
+    const float r[4][4] = {{c, s, 0.0f, 0.0f}, {-s, c, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 1.0f}};
+    for (int k = 0; k < 4; ++k) {
+        float t0[4], t1[4], t2[4], t3[4];
+        vec4_scale(t0, a, r[k][0]);
+        vec4_scale(t1, b, r[k][1]);
+        vec4_scale(t2, cc, r[k][2]);
+        vec4_scale(t3, d, r[k][3]);
+        for (int e = 0; e < 4; ++e) m[4 * k + e] = ((t0[e] + t1[e]) + t2[e]) + t3[e];
+    }
+}
+
+NBO_API void nbo_instances(const float *pos3, const float *vel3, float *inst16, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) instance_matrix(inst16 + 16 * (size_t)i, pos3 + 3 * (size_t)i, vel3 + 3 * (size_t)i);
+}
+
+/* ------------------------------------------------------------------------------------
+ * One step for bodies [first, first+count) against the start-of-step snapshot.
+ *   old_pos3  : snapshot of ALL n_total positions   (main.rs:415 old_positions)
+ *   pos3_out  : count new positions, local index (i - first)
+ *   vel3      : count velocities, updated in place, local index
+ *   inst16    : count matrices or NULL
+ * The per-body closure is src/main.rs:424-440.
+ * ---------------------------------------------------------------------------------- */
+NBO_API void nbo_step_range(const float *old_pos3, float *pos3_out, float *vel3, float *inst16, uint32_t n_total,
+                            uint32_t first, uint32_t count, float dt, float G, float bias)
+{
+    for (uint32_t l = 0; l < count; ++l) {
+        const uint32_t n = first + l;
+        /* boid_n_pos equals old_positions[n]: it was copied at main.rs:415 and is not yet written */
+        const float pnx = old_pos3[3 * (size_t)n + 0];
+        const float pny = old_pos3[3 * (size_t)n + 1];
+        const float pnz = old_pos3[3 * (size_t)n + 2];
+        /* main.rs:425-426: fold from Vector3::new(0.0, 0.0, 0.0), i = 0..n_total-1 in order, self included */
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const float pix = old_pos3[3 * (size_t)i + 0];
+            const float piy = old_pos3[3 * (size_t)i + 1];
+            const float piz = old_pos3[3 * (size_t)i + 2];
+            /* main.rs:428  vec = boid_i_pos.to_vec() - boid_n_pos.to_vec() */
+            const float vx = pix - pnx, vy = piy - pny, vz = piz - pnz;
+            /* main.rs:429  dist = boid_n_pos.distance2(*boid_i_pos) + bias; distance2 = (other - self).magnitude2() */
+            const float ex = pix - pnx, ey = piy - pny, ez = piz - pnz;
+            const float xx = ex * ex, yy = ey * ey, zz = ez * ez;
+            const float d2 = (xx + yy) + zz;
+            const float dist = d2 + bias;
+            /* main.rs:430  sum + (vec * G / dist)  ==  sum + ((vec * G) / dist) */
+            const float gx = vx * G, gy = vy * G, gz = vz * G;
+            const float qx = gx / dist, qy = gy / dist, qz = gz / dist;
+            sx = sx + qx;
+            sy = sy + qy;
+            sz = sz + qz;
+        }
+        /* main.rs:434  *boid_n_vel = *boid_n_vel + gravity * dt */
+        float *v = vel3 + 3 * (size_t)l;
+        const float ax = sx * dt, ay = sy * dt, az = sz * dt;
+        v[0] = v[0] + ax;
+        v[1] = v[1] + ay;
+        v[2] = v[2] + az;
+        /* main.rs:436  *boid_n_pos = Point3::from_vec(boid_n_vel.clone() + boid_n_pos.to_vec())   (no dt) */
+        float *p = pos3_out + 3 * (size_t)l;
+        p[0] = v[0] + pnx;
+        p[1] = v[1] + pny;
+        p[2] = v[2] + pnz;
+        /* main.rs:437-439 */
+        if (inst16) instance_matrix(inst16 + 16 * (size_t)l, p, v);
+    }
+}
+
+/* The outer loop over bodies is rayon's par_iter_mut (main.rs:420-424).  Bodies are
+ * independent within a step, so the thread count changes scheduling only, never bits.
+ * Threads live for the whole run and meet at a barrier twice per step (after the snapshot
+ * copy, after the update). */
+typedef struct {
+    float *old_pos3;
+    float *pos3;
+    float *vel3;
+    float *inst16;
+    uint32_t n, k, first, count;
+    float dt, G, bias;
+    int tid;
+    pthread_barrier_t *bar;
+} nbo_job;
+
+static void *nbo_worker(void *arg)
+{
+    nbo_job *j = (nbo_job *)arg;
+    for (uint32_t s = 0; s < j->k; ++s) {
+        /* main.rs:415  old_positions.copy_from_slice(positions); main.rs:416 also copies the
+         * velocities, but update_instance_nbody never reads that copy */
+        if (j->tid == 0) memcpy(j->old_pos3, j->pos3, sizeof(float) * 3 * (size_t)j->n);
+        if (j->bar) pthread_barrier_wait(j->bar);
+        float *inst = (j->inst16 && s + 1 == j->k) ? j->inst16 + 16 * (size_t)j->first : NULL;
+        nbo_step_range(j->old_pos3, j->pos3 + 3 * (size_t)j->first, j->vel3 + 3 * (size_t)j->first, inst, j->n, j->first,
+                       j->count, j->dt, j->G, j->bias);
+        if (j->bar) pthread_barrier_wait(j->bar);
+    }
+    return NULL;
+}
+
+/* update_instance_nbody (main.rs:404-441) applied k times.  inst16 may be NULL; when given it
+ * holds the matrices of the LAST step, as the caller at main.rs:932-936 would see them. */
+NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, float dt, float G, float bias,
+                    int nthreads)
+{
+    float *old = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    if (!old) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n) nthreads = n ? (int)n : 1;
+    if (nthreads == 1) {
+        nbo_job job = {old, pos3, vel3, inst16, n, k, 0, n, dt, G, bias, 0, NULL};
+        nbo_worker(&job);
+        free(old);
+        return 0;
+    }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)nthreads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    nbo_job *jobs = (nbo_job *)malloc(sizeof(nbo_job) * (size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        uint32_t lo = (uint32_t)(((uint64_t)n * (uint64_t)t) / (uint64_t)nthreads);
+        uint32_t hi = (uint32_t)(((uint64_t)n * (uint64_t)(t + 1)) / (uint64_t)nthreads);
+        jobs[t] = (nbo_job){old, pos3, vel3, inst16, n, k, lo, hi - lo, dt, G, bias, t, &bar};
+        pthread_create(&th[t], NULL, nbo_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(th);
+    free(old);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * binary64 variant of the same recurrence: NOT the reference's arithmetic -- it exists to
+ * show the rounding-noise floor of the chaotic system (sixth finding).
+ * ---------------------------------------------------------------------------------- */
+NBO_API int nbo_run_f64(double *pos3, double *vel3, uint32_t n, uint32_t k, double dt, double G, double bias)
+{
+    double *old = (double *)malloc(sizeof(double) * 3 * (size_t)(n ? n : 1));
+    if (!old) return -1;
+    for (uint32_t s = 0; s < k; ++s) {
+        memcpy(old, pos3, sizeof(double) * 3 * (size_t)n);
+        for (uint32_t b = 0; b < n; ++b) {
+            double sx = 0, sy = 0, sz = 0;
+            const double px = old[3 * (size_t)b], py = old[3 * (size_t)b + 1], pz = old[3 * (size_t)b + 2];
+            for (uint32_t i = 0; i < n; ++i) {
+                const double vx = old[3 * (size_t)i] - px, vy = old[3 * (size_t)i + 1] - py, vz = old[3 * (size_t)i + 2] - pz;
+                const double dist = ((vx * vx + vy * vy) + vz * vz) + bias;
+                sx = sx + (vx * G) / dist;
+                sy = sy + (vy * G) / dist;
+                sz = sz + (vz * G) / dist;
+            }
+            double *v = vel3 + 3 * (size_t)b, *p = pos3 + 3 * (size_t)b;
+            v[0] = v[0] + sx * dt;
+            v[1] = v[1] + sy * dt;
+            v[2] = v[2] + sz * dt;
+            p[0] = v[0] + px;
+            p[1] = v[1] + py;
+            p[2] = v[2] + pz;
+        }
+    }
+    free(old);
+    return 0;
+}

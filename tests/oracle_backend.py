@@ -1,0 +1,29 @@
+"""A compute backend for nenbody_amd.dist.ShardedScene that runs the CPU oracle on CPU tensors.
+
+TEST-ONLY: it lets the world_size > 1 orchestration (partition, per-step all-gather, buffer ping-pong) be
+exercised under the gloo backend on a machine with no GPU.  The product backend is HipBackend.
+"""
+import numpy as np
+import torch
+
+import oracle
+
+
+class OracleBackend:
+    name = "oracle-test"
+
+    def scratch_bytes(self, params, n_total, count):
+        return 0
+
+    def step(self, params, n_total, first, count, pos_in, pos_out, vel, scratch):
+        old = pos_in[:n_total, :3].contiguous().numpy()
+        v = vel[:count, :3].contiguous().numpy()
+        p_new, v_new = oracle.step_range(old, v, first, count, np.float32(params.dt), np.float32(params.G),
+                                         np.float32(params.bias))
+        pos_out[first:first + count, :3] = torch.from_numpy(p_new)
+        pos_out[first:first + count, 3] = 0
+        vel[:count, :3] = torch.from_numpy(v_new)
+
+    def instances(self, count, pos, vel, inst):
+        m = oracle.instances(pos[:count, :3].contiguous().numpy(), vel[:count, :3].contiguous().numpy())
+        inst[:count] = torch.from_numpy(m.reshape(count, 16))

@@ -1,0 +1,140 @@
+"""CPU tests of the C-ABI shared library: it loads, exports exactly what include/nenbody.h declares,
+validates arguments on the host, and -- with no GPU -- refuses to compute instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "nenbody.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nb_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_declare_the_same_symbols(nb):
+    from nenbody_amd import _lib
+
+    assert declared_functions() == sorted(_lib.PROTOTYPES)
+
+
+def test_library_exports_every_declared_symbol(nb):
+    lib = ctypes.CDLL(nb._lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"libnenbody_hip.so does not export {name}"
+
+
+def test_abi_version_and_default_params(nb):
+    from nenbody_amd import _lib
+
+    assert _lib.load().nb_abi_version() == _lib.NB_ABI_VERSION
+    text = open(HEADER).read()
+    assert int(re.search(r"#define NB_ABI_VERSION (\d+)", text).group(1)) == _lib.NB_ABI_VERSION
+    p = nb.default_params()
+    # src/main.rs:411-413
+    assert p.dt == np.float32(0.1) and p.G == np.float32(0.001) and p.bias == np.float32(0.0000001)
+    assert p.tile == 0 and p.mode == nb.NB_MODE_STRICT
+
+
+def test_init_state_matches_the_oracles_generator(nb, oracle):
+    for n, seed in [(1, 0), (33, 1234), (1000, 7)]:
+        p, v = nb.init_state(n, seed)
+        po, vo = oracle.init_state(n, seed)
+        assert (p.view(np.uint32) == po.view(np.uint32)).all() and (v.view(np.uint32) == vo.view(np.uint32)).all()
+
+
+def _create(nb, n, ndev, params):
+    from nenbody_amd import _lib
+
+    ctx = ctypes.c_void_p()
+    rc = _lib.load().nb_create(n, ndev, ctypes.byref(params) if params is not None else None, ctypes.byref(ctx))
+    return rc, ctx
+
+
+def test_create_rejects_bad_arguments_before_touching_the_device(nb):
+    from nenbody_amd import _lib
+
+    p = nb.default_params()
+    rc, _ = _create(nb, 0, 1, p)
+    assert rc == _lib.NB_ERR_INVALID and "count" in _lib.last_error()
+    rc, _ = _create(nb, 16, 2, p)
+    assert rc == _lib.NB_ERR_UNSUPPORTED and "one process" in _lib.last_error()
+    bad = nb.default_params()
+    bad.mode = 7
+    rc, _ = _create(nb, 16, 1, bad)
+    assert rc == _lib.NB_ERR_INVALID and "mode" in _lib.last_error()
+    bad = nb.default_params()
+    bad.tile = 100
+    rc, _ = _create(nb, 16, 1, bad)
+    assert rc == _lib.NB_ERR_INVALID and "tile" in _lib.last_error()
+    assert _lib.load().nb_create(16, 1, None, None) == _lib.NB_ERR_INVALID
+
+
+def test_launch_step_validates_pointers_and_ranges(nb):
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    p = nb.default_params()
+    fake_a, fake_b, fake_v = 0x1000, 0x2000, 0x3000   # never dereferenced: validation fails first
+    assert lib.nb_launch_step(ctypes.byref(p), 16, 0, 16, None, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_step(ctypes.byref(p), 16, 0, 16, fake_a, fake_a, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    assert "alias" in _lib.last_error()
+    assert lib.nb_launch_step(ctypes.byref(p), 16, 8, 9, fake_a, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    assert "exceeds" in _lib.last_error()
+    assert lib.nb_launch_step(ctypes.byref(p), 16, 0, 0, fake_a, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    need = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
+    assert need > 0   # small shard of a large set: the j range is split, partial sums need scratch
+    assert lib.nb_launch_step(ctypes.byref(fast), 131072, 0, 16384, fake_a, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    assert "scratch" in _lib.last_error()
+
+
+def test_scratch_bytes_host_arithmetic(nb):
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    strict = nb.default_params()
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 0   # STRICT never splits the fold
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    b = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
+    assert b % (16384 * 16) == 0 and 2 <= b // (16384 * 16) <= 64
+    assert lib.nb_scratch_bytes(ctypes.byref(fast), 10, 20) == 0             # invalid shape -> 0
+
+
+def test_no_device_means_no_compute(nb):
+    """The product has no CPU path: without a GPU the context cannot even be created."""
+    from nenbody_amd import _lib
+
+    if _lib.load().nb_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(nb.NbError) as ei:
+        nb.Scene.new(64)
+    assert ei.value.status == _lib.NB_ERR_NO_DEVICE and "no CPU path" in str(ei.value)
+    pos, vel = nb.init_state(8)
+    inst = np.zeros((8, 4, 4), np.float32)
+    with pytest.raises(nb.NbError):
+        nb.update_instance_nbody(inst, pos, pos.copy(), vel, vel.copy())
+    with pytest.raises(nb.NbError):
+        nb.ShardedScene(pos, vel)
+
+
+def test_update_instance_nbody_argument_contract(nb):
+    """Errors the reference raises before computing anything (copy_from_slice panics on a length mismatch, main.rs:415-416)."""
+    pos, vel = nb.init_state(8)
+    inst = np.zeros((8, 4, 4), np.float32)
+    with pytest.raises(ValueError, match="old_positions"):
+        nb.update_instance_nbody(inst, pos, np.zeros((7, 3), np.float32), vel, vel.copy())
+    with pytest.raises(ValueError, match="old_velocities"):
+        nb.update_instance_nbody(inst, pos, pos.copy(), vel, np.zeros((9, 3), np.float32))
+    with pytest.raises(TypeError):
+        nb.update_instance_nbody(inst, pos.astype(np.float64), pos.copy(), vel, vel.copy())
+    # an empty zip updates nothing but still takes the snapshot copies (main.rs:415-416 run first)
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    nb.update_instance_nbody(np.zeros((0, 4, 4), np.float32), pos, old_p, vel, old_v)
+    assert (old_p == pos).all() and (old_v == vel).all()

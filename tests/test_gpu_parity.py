@@ -1,0 +1,377 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Bar: STRICT is bit-identical to the oracle (the reference's binary32 arithmetic) for any N, any K, any
+sharding.  FAST is held to stated tolerances over short horizons (the system is chaotic after ~300 steps
+at N=1024: SURVEY.md section 0, sixth finding -- no reassociated fp32 kernel can track it further).
+north_star tolerance: |delta r| < 1e-4 after 1 000 steps; STRICT meets it with |delta r| = 0.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(got, ref, what=""):
+    g, r = bits(got), bits(ref)
+    if not (g == r).all():
+        bad = np.argwhere(g != r)
+        raise AssertionError(f"{what}: {len(bad)} of {g.size} words differ; first at {bad[0]}: "
+                             f"{np.asarray(got).ravel()[np.ravel_multi_index(tuple(bad[0]), g.shape)]!r} vs "
+                             f"{np.asarray(ref).ravel()[np.ravel_multi_index(tuple(bad[0]), r.shape)]!r}")
+
+
+def state3d(oracle, n, seed):
+    pos, vel = oracle.init_state(n, seed)
+    rng = np.random.default_rng(seed)
+    pos[:, 2] = rng.uniform(-100, 100, n).astype(np.float32)
+    vel[:, 2] = rng.uniform(0, 0.1, n).astype(np.float32)
+    return pos, vel
+
+
+# ---------------------------------------------------------------------------------------------------------
+# STRICT: bit-exact
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 1025, 2049])
+def test_strict_ragged_sizes_bit_exact(nb, oracle, n):
+    pos, vel = state3d(oracle, n, seed=n)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(3)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 3)
+    assert_bits_equal(p, p_ref, f"positions n={n}")
+    assert_bits_equal(v, v_ref, f"velocities n={n}")
+
+
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_strict_every_tile_size_bit_exact(nb, oracle, tile):
+    pos, vel = state3d(oracle, 3000, seed=tile)
+    with nb.Scene(pos, vel, nb.default_params(tile=tile)) as sc:
+        sc.step_n(2)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 2)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_strict_golden_n16_and_n1024(nb):
+    g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden.npz"))
+    seed = int(g["seed"][0])
+    pos, vel = nb.init_state(16, seed)
+    assert_bits_equal(pos, g["n16_init_pos"])
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        assert_bits_equal(sc.positions(), g["n16_k1_pos"])
+        sc.step_n(9)
+        assert_bits_equal(sc.positions(), g["n16_k10_pos"])
+        assert_bits_equal(sc.velocities(), g["n16_k10_vel"])
+        assert np.allclose(sc.instances(), g["n16_k10_inst"], rtol=0, atol=1e-6)
+    pos, vel = nb.init_state(1024, seed)
+    with nb.Scene(pos, vel) as sc:
+        done = 0
+        for k in (1, 10, 100, 1000):   # north_star: positions after 1 000 steps, |dr| < 1e-4 -- here exactly 0
+            sc.step_n(k - done)
+            done = k
+            assert_bits_equal(sc.positions(), g[f"n1024_k{k}_pos"], f"n1024 k={k} pos")
+            assert_bits_equal(sc.velocities(), g[f"n1024_k{k}_vel"], f"n1024 k={k} vel")
+        assert np.allclose(sc.instances(), g["n1024_k1000_inst"], rtol=0, atol=1e-6)
+
+
+def test_strict_config2_n16384_vs_oracle_and_golden(nb, oracle):
+    """BASELINE config 2: N=16 384, one GPU, checked against the CPU path."""
+    g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden.npz"))
+    pos, vel = nb.init_state(16384, int(g["seed"][0]))
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(5)
+        p, v = sc.state()
+    idx = g["n16384_k5_sample_idx"]
+    assert_bits_equal(p[idx], g["n16384_k5_sample_pos"])
+    assert_bits_equal(v[idx], g["n16384_k5_sample_vel"])
+    assert np.bitwise_xor.reduce(bits(p).ravel()) == g["n16384_k5_xor"][0]
+    assert np.bitwise_xor.reduce(bits(v).ravel()) == g["n16384_k5_xor"][1]
+    p_ref, v_ref = oracle.run(pos, vel, 5)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_strict_ieee_fallback_path_bit_exact(nb, oracle, monkeypatch):
+    """The guarded '/' path (taken when coordinates leave the range where the shared-reciprocal ladder is
+    proven exact) must give the same bits; force it for every tile."""
+    pos, vel = state3d(oracle, 1500, seed=77)
+    monkeypatch.setenv("NB_STRICT_FORCE_IEEE", "1")
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(3)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 3)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_strict_extreme_coordinates_bit_exact(nb, oracle):
+    """Data that trips the per-tile range guard: tiny, huge, subnormal-producing and coincident coordinates,
+    mixed into ordinary ones so that some tiles take the ladder and others the IEEE path."""
+    n = 2048
+    pos, vel = state3d(oracle, n, seed=5)
+    pos[5] = [1e-30, -3e-25, 0.0]          # |x| far below the ladder's lower bound
+    pos[6] = [1e-30, -3e-25, 1e-38]        # nearly coincident with body 5: dx underflows, subnormal products
+    pos[700] = [3e7, -2e7, 1e7]            # above the upper bound: r^2 ~ 1e15
+    pos[701] = pos[700]                    # exactly coincident pair
+    pos[1500] = [1e-45, 1e-44, -1e-45]     # subnormal coordinates
+    pos[2047] = [-2e6, 5e-12, 1.5e6]
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(2)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 2)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_strict_nonfinite_input_propagates_like_the_reference(nb, oracle):
+    pos, vel = state3d(oracle, 300, seed=9)
+    pos[17, 0] = np.inf
+    pos[200, 1] = np.nan
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 1)
+    assert (np.isnan(p) == np.isnan(p_ref)).all() and (np.isnan(v) == np.isnan(v_ref)).all()
+    ok = ~np.isnan(p_ref)
+    assert (bits(p)[ok] == bits(p_ref)[ok]).all()
+
+
+def test_strict_nondefault_constants_bit_exact(nb, oracle):
+    pos, vel = state3d(oracle, 700, seed=21)
+    for dt, g_, bias in [(0.05, 0.5, 0.01), (1.0, -0.001, 1e-3), (0.1, 1e-30, 1e-7), (0.1, 0.001, 0.0)]:
+        params = nb.default_params()
+        params.dt, params.G, params.bias = dt, g_, bias
+        if bias == 0.0:
+            pos2 = pos.copy()      # bias 0: the self term is 0/0 = NaN in the reference; keep the comparison NaN-aware
+        else:
+            pos2 = pos
+        with nb.Scene(pos2, vel, params) as sc:
+            sc.step_n(2)
+            p, v = sc.state()
+        p_ref, v_ref = oracle.run(pos2, vel, 2, np.float32(dt), np.float32(g_), np.float32(bias))
+        assert (np.isnan(p) == np.isnan(p_ref)).all()
+        ok = ~np.isnan(p_ref)
+        assert (bits(p)[ok] == bits(p_ref)[ok]).all(), (dt, g_, bias)
+        okv = ~np.isnan(v_ref)
+        assert (bits(v)[okv] == bits(v_ref)[okv]).all(), (dt, g_, bias)
+
+
+def test_strict_is_deterministic(nb, oracle):
+    pos, vel = state3d(oracle, 5000, seed=31)
+    outs = []
+    for _ in range(2):
+        with nb.Scene(pos, vel) as sc:
+            sc.step_n(4)
+            outs.append(sc.state())
+    assert_bits_equal(outs[0][0], outs[1][0])
+    assert_bits_equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launch API / sharding (one process, several index ranges): what each rank of a multi-GPU job runs
+# ---------------------------------------------------------------------------------------------------------
+def _sharded_step_on_one_gpu(nb, pos, vel, parts, params, steps):
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    be = HipBackend()
+    n = len(pos)
+    dev = torch.device("cuda", 0)
+    cur = torch.zeros((n, 4), dtype=torch.float32)
+    cur[:, :3] = torch.from_numpy(pos)
+    cur = cur.to(dev)
+    nxt = torch.zeros_like(cur)
+    vels = []
+    for first, count in parts:
+        vr = torch.zeros((count, 4), dtype=torch.float32)
+        vr[:, :3] = torch.from_numpy(vel[first:first + count])
+        vels.append(vr.to(dev))
+    for _ in range(steps):
+        for (first, count), vr in zip(parts, vels):
+            sb = be.scratch_bytes(params, n, count)
+            scratch = torch.empty((sb,), dtype=torch.uint8, device=dev) if sb else None
+            be.step(params, n, first, count, cur, nxt, vr, scratch)
+        cur, nxt = nxt, cur
+    torch.cuda.synchronize()
+    v = np.concatenate([vr[:, :3].cpu().numpy() for vr in vels])
+    return cur[:, :3].cpu().numpy(), v
+
+
+@pytest.mark.parametrize("parts", [[(0, 1000)], [(0, 500), (500, 500)], [(0, 1), (1, 255), (256, 257), (513, 487)]])
+def test_strict_sharded_launch_equals_unsharded(nb, oracle, parts):
+    pos, vel = state3d(oracle, 1000, seed=11)
+    p, v = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(), 3)
+    p_ref, v_ref = oracle.run(pos, vel, 3)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_sharded_scene_world_of_one_on_gpu(nb, oracle):
+    pos, vel = state3d(oracle, 777, seed=13)
+    sc = nb.ShardedScene(pos, vel)
+    sc.step_n(3)
+    sc.sync()
+    p_ref, v_ref, inst_ref = oracle.run(pos, vel, 3, want_instances=True)
+    assert_bits_equal(sc.positions(), p_ref)
+    assert_bits_equal(sc.velocities(), v_ref)
+    assert np.allclose(sc.local_instances(), inst_ref, rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full BASELINE size, N = 131 072: size-independent properties + an oracle check on sampled bodies
+# ---------------------------------------------------------------------------------------------------------
+def test_strict_full_size_sampled_bodies_vs_oracle_and_shard_invariance(nb, oracle):
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        p, v = sc.state()
+    # (1) 320 bodies spread over first/last/middle workgroups, each folded over all 131 072 j's by the oracle
+    idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(n - 64, n), np.linspace(64, n - 65, 192).astype(np.int64)]))
+    for i in idx:
+        p_ref, v_ref = oracle.step_range(pos, vel[i:i + 1], int(i), 1)
+        assert (bits(p[i]) == bits(p_ref[0])).all() and (bits(v[i]) == bits(v_ref[0])).all(), f"body {i}"
+    # (2) antisymmetry of the pair force: the total acceleration cancels to rounding
+    a = (v.astype(np.float64) - vel.astype(np.float64)) / 0.1
+    assert np.abs(a.sum(axis=0)).max() < 1e-2 * np.abs(a).sum(axis=0).max()
+    # (3) planar input stays planar, exactly (z = 0, vz = 0 is a fixed point of the reference's arithmetic)
+    assert (p[:, 2] == 0).all() and (v[:, 2] == 0).all()
+    # (4) an 8-way index-range sharding of the same step gives the same bits
+    parts = nb.partition(n, 8)
+    p8, v8 = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(), 1)
+    assert_bits_equal(p8, p)
+    assert_bits_equal(v8, v)
+
+
+def test_fast_full_size_close_to_strict_and_shard_consistent(nb):
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        p_s, v_s = sc.state()
+    with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+        sc.step_n(1)
+        p_f, v_f = sc.state()
+    acc = np.abs(v_s - vel).max()
+    assert np.abs(v_f - v_s).max() <= 2e-5 * acc + 1e-9      # per-step relative force error, tolerance 2e-5 of the largest
+    assert np.abs(p_f - p_s).max() <= 1e-4                    # north_star's |dr| bound, one step
+    parts = nb.partition(n, 8)
+    p8, v8 = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(mode=nb.NB_MODE_FAST), 1)
+    assert np.abs(p8 - p_s).max() <= 1e-4 and np.abs(v8 - v_s).max() <= 2e-5 * acc + 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FAST: stated tolerances
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,tol_r", [(1024, 1, 1e-6), (1024, 10, 1e-5), (1024, 100, 1e-4), (16384, 10, 1e-4), (1000, 10, 1e-5)])
+def test_fast_within_tolerance_of_oracle(nb, oracle, n, k, tol_r):
+    """|delta r| bound of north_star (1e-4) over horizons where a reassociated fp32 sum can meet it."""
+    pos, vel = oracle.init_state(n, 1234)
+    with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+        sc.step_n(k)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    dr = np.linalg.norm(p.astype(np.float64) - p_ref.astype(np.float64), axis=1).max()
+    assert dr < tol_r, f"max |dr| = {dr:.3e} after {k} steps"
+
+
+@pytest.mark.parametrize("ib,slices,tile", [(1, 1, 256), (2, 1, 512), (4, 1, 1024), (1, 4, 256), (2, 7, 512), (4, 64, 256)])
+def test_fast_every_launch_shape(nb, oracle, monkeypatch, ib, slices, tile):
+    monkeypatch.setenv("NB_FAST_IB", str(ib))
+    monkeypatch.setenv("NB_FAST_SLICES", str(slices))
+    n = 5000
+    pos, vel = state3d(oracle, n, seed=ib * 100 + slices)
+    with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST, tile=tile)) as sc:
+        sc.step_n(1)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 1)
+    acc = np.abs(v_ref - vel).max()
+    assert np.abs(v - v_ref).max() <= 2e-5 * acc + 1e-9
+    assert np.abs(p - p_ref).max() <= 1e-5
+
+
+def test_fast_is_deterministic(nb, oracle, monkeypatch):
+    monkeypatch.setenv("NB_FAST_SLICES", "8")
+    pos, vel = state3d(oracle, 4096, seed=41)
+    outs = []
+    for _ in range(2):
+        with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+            sc.step_n(3)
+            outs.append(sc.state())
+    assert_bits_equal(outs[0][0], outs[1][0])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's operator interface
+# ---------------------------------------------------------------------------------------------------------
+def test_update_instance_nbody_matches_reference_semantics(nb, oracle):
+    n = 300
+    pos, vel = state3d(oracle, n, seed=51)
+    p_ref, v_ref, inst_ref = oracle.run(pos, vel, 1, want_instances=True)
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n, 4, 4), np.float32)
+    nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+    assert_bits_equal(old_p, pos)          # main.rs:415
+    assert_bits_equal(old_v, vel)          # main.rs:416
+    assert_bits_equal(positions, p_ref)
+    assert_bits_equal(velocities, v_ref)
+    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    assert (inst[:, 3, :3] == positions).all()       # translation column is the new position, exactly
+
+
+def test_update_instance_nbody_zip_truncation(nb, oracle):
+    """instances shorter than positions: only that many bodies move, the fold still sees everyone (main.rs:420-425)."""
+    n, m = 200, 50
+    pos, vel = state3d(oracle, n, seed=52)
+    p_ref, v_ref = oracle.step_range(pos, vel[:m], 0, m)
+    positions, velocities = pos.copy(), vel.copy()
+    inst = np.zeros((m, 4, 4), np.float32)
+    nb.update_instance_nbody(inst, positions, np.zeros_like(pos), velocities, np.zeros_like(vel))
+    assert_bits_equal(positions[:m], p_ref)
+    assert_bits_equal(velocities[:m], v_ref)
+    assert_bits_equal(positions[m:], pos[m:])
+    assert_bits_equal(velocities[m:], vel[m:])
+
+
+def test_scene_step_refreshes_host_mirrors(nb, oracle):
+    pos, vel = state3d(oracle, 100, seed=53)
+    with nb.Scene.from_state(pos, vel) as sc:
+        sc.step()
+        p1, v1, i1 = sc._positions.copy(), sc._velocities.copy(), sc._instances.copy()
+        assert sc.steps_done == 1
+    p_ref, v_ref, inst_ref = oracle.run(pos, vel, 1, want_instances=True)
+    assert_bits_equal(p1, p_ref)
+    assert_bits_equal(v1, v_ref)
+    assert np.allclose(i1, inst_ref, rtol=0, atol=1e-6)
+
+
+def test_instances_edge_cases(nb, oracle):
+    pos = np.array([[1, 2, 3], [0, 0, 0], [-5, 1e6, -1e-6], [7, 7, 7]], np.float32)
+    vel = np.array([[0, 0, 0], [-1, 0, 0], [0, -2, 5], [1e-20, 1e-20, 0]], np.float32)   # atan2(0,0)=0; heading -x; -y
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    dev = torch.device("cuda", 0)
+    pr = torch.zeros((4, 4)); pr[:, :3] = torch.from_numpy(pos)
+    vr = torch.zeros((4, 4)); vr[:, :3] = torch.from_numpy(vel)
+    inst = torch.zeros((4, 16), device=dev)
+    HipBackend().instances(4, pr.to(dev), vr.to(dev), inst)
+    torch.cuda.synchronize()
+    got = inst.cpu().numpy().reshape(4, 4, 4)
+    ref = oracle.instances(pos, vel)
+    assert np.allclose(got, ref, rtol=0, atol=1e-6)
+    assert (got[:, 3, :3] == pos).all() and (got[:, 3, 3] == 1).all() and (got[:, 2] == [0, 0, 1, 0]).all()
