@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Throughput sweep of the step kernels over N and launch shape (diagnostic tool; needs a GPU).
+
+    python tools/sweep.py strict            # STRICT over N and tile
+    python tools/sweep.py fast              # FAST over N, bodies/thread, j slices, tile
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nenbody_amd as nb  # noqa: E402
+
+
+def run(n, mode, steps, env):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    pos, vel = nb.init_state(n, 1234)
+    with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
+        sc.step_n(2)
+        sc.sync()
+        t0 = time.perf_counter()
+        sc.step_n(steps)
+        sc.sync()
+        dt = (time.perf_counter() - t0) / steps
+    for k in env:
+        os.environ.pop(k, None)
+    pairs = float(n) * n / dt
+    print(f"mode={'strict' if mode == 0 else 'fast'} n={n:8d} {env} ms/step={dt * 1e3:9.3f} pairs/s={pairs:.3e} "
+          f"TF18={pairs * 18 / 1e12:6.1f} ({pairs * 18 / 157.3e12 * 100:4.1f}%)", flush=True)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "strict"
+    if what == "strict":
+        for n in (32768, 65536, 131072, 262144, 524288):
+            for tile in (256, 512, 1024):
+                run(n, nb.NB_MODE_STRICT, max(2, min(10, int(2e11 / (n * n)))), {"NB_TILE": tile})
+        run(131072, nb.NB_MODE_STRICT, 5, {"NB_TILE": 256, "NB_STRICT_FORCE_IEEE": 1})
+    else:
+        for n in (16384, 131072, 1048576):
+            for ib in (1, 2, 4):
+                for sl in (1, 2, 4, 8, 16):
+                    if n == 1048576 and sl > 2:
+                        continue
+                    run(n, nb.NB_MODE_FAST, max(2, min(20, int(4e11 / (n * n)))), {"NB_FAST_IB": ib, "NB_FAST_SLICES": sl, "NB_TILE": 512})
+        for tile in (256, 1024):
+            run(131072, nb.NB_MODE_FAST, 10, {"NB_FAST_IB": 2, "NB_FAST_SLICES": 4, "NB_TILE": tile})
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters, float seed)
     uint64_t t0 = __builtin_amdgcn_s_memtime();
     uint64_t r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int rep = 0; rep < 8; ++rep) {
         if (KIND == K_FMA) {
 #define X(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n\t"
             asm volatile(REP8(X) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters, float seed)
                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(a6), "+v"(a7)
                 : "v"(pb), "v"(pc));
         }
+      }
     }
     uint64_t t1 = __builtin_amdgcn_s_memtime();
     uint64_t r1 = __builtin_amdgcn_s_memrealtime();
@@ -146,13 +149,15 @@ static void run(int waves_per_simd, int iters)
     }
     std::sort(cyc.begin(), cyc.end());
     std::sort(clk.begin(), clk.end());
-    const double ninst = (double)iters * insts_per_iter[KIND];
+    const double ninst = (double)iters * 8.0 * insts_per_iter[KIND];
     const double cyc_per_inst_wave = cyc[waves / 2] / ninst;                 // one wave's view
     const double cyc_per_inst_simd = cyc_per_inst_wave / waves_per_simd;    // SIMD throughput view
     const double wall_inst_rate = ninst * waves / (ms * 1e-3);               // wave-instructions / s, chip
+    const double wall_cyc_per_inst_simd = (ms * 1e-3) * (clk[waves / 2] * 1e6) / ninst / waves_per_simd;
+    printf("[cus=%d] ", cus);
     printf("%-20s waves/SIMD=%d  cyc/inst(one wave)=%6.2f  cyc/inst(SIMD)=%5.2f  clock=%5.0f MHz  wall=%.3f ms  "
-           "chip wave-inst/s=%.3e\n",
-           kind_name[KIND], waves_per_simd, cyc_per_inst_wave, cyc_per_inst_simd, clk[waves / 2], ms, wall_inst_rate);
+           "chip wave-inst/s=%.3e  wall-cyc/inst(SIMD)=%.2f\n",
+           kind_name[KIND], waves_per_simd, cyc_per_inst_wave, cyc_per_inst_simd, clk[waves / 2], ms, wall_inst_rate, wall_cyc_per_inst_simd);
     hipFree(d);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
@@ -160,7 +165,7 @@ static void run(int waves_per_simd, int iters)
 
 int main(int argc, char **argv)
 {
-    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     const int wps[] = {1, 2, 4, 8};
     for (int w : wps) {
         run<K_FMA>(w, iters);
