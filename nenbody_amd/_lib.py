@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnenbody_hip.so")
+# NENBODY_LIB overrides the path (kernel experiments: a second build of the same sources with other flags)
+LIB_PATH = os.environ.get("NENBODY_LIB") or os.path.join(_HERE, "lib", "libnenbody_hip.so")
 
 NB_ABI_VERSION = 1
 NB_OK = 0

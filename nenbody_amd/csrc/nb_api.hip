@@ -19,8 +19,9 @@ namespace {
 
 thread_local std::string g_tls_error = "";
 
-// MI355X: 256 CUs x 4 SIMDs.  FAST launches aim at >= 4 waves per SIMD.
-constexpr uint32_t kTargetWaves = 4096;
+// MI355X: 256 CUs x 4 SIMDs.  FAST launches aim at 16 waves per SIMD's worth of work items: about twice what
+// is resident at once, which evens out the tail (measured: profiles/r01_first/sweep_fast.log).
+constexpr uint32_t kTargetWaves = 16384;
 constexpr uint32_t kMaxSlices = 64;
 
 int env_u32(const char *name, uint32_t *out)
@@ -39,6 +40,8 @@ struct Plan {
     uint32_t slices;  // FAST: blockIdx.y slices of the j range
     uint32_t j_chunk;
     uint32_t lo_bits, hi_bits, force_ieee;  // STRICT guard
+    uint32_t force_3d;                      // 2 = never take the planar shortcut (NB_FORCE_3D=1: tests, measurements)
+    uint32_t unroll;                        // STRICT: pairs in flight per lane (4 or 8)
 };
 
 int floor_log2f(float x)
@@ -73,7 +76,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     pl.slices = 1;
     pl.j_chunk = n_total;
     if (p.mode == NB_MODE_FAST) {
-        pl.ib = (count >= 65536u) ? 2u : 1u;
+        pl.ib = (count >= 65536u) ? 4u : (count >= 32768u) ? 2u : 1u;
         env_u32("NB_FAST_IB", &pl.ib);
         if (pl.ib != 1 && pl.ib != 2 && pl.ib != 4) pl.ib = 1;
         const uint32_t blocks = (count + 256u * pl.ib - 1u) / (256u * pl.ib);
@@ -112,6 +115,11 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     }
     uint32_t f = 0;
     if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
+    f = 0;
+    pl.force_3d = (env_u32("NB_FORCE_3D", &f) && f) ? 2u : 0u;
+    pl.unroll = 4;
+    env_u32("NB_STRICT_UNROLL", &pl.unroll);
+    if (pl.unroll != 4 && pl.unroll != 8) pl.unroll = 4;
     *out = pl;
     return NB_OK;
 }
@@ -138,8 +146,9 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.lo_bits = pl.lo_bits;
     a.hi_bits = pl.hi_bits;
     a.force_ieee = pl.force_ieee;
+    a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
-    hipError_t e = (p.mode == NB_MODE_STRICT) ? nbk::launch_strict(a, pl.tile, stream)
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? nbk::launch_strict(a, pl.tile, pl.unroll, stream)
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
     if (e != hipSuccess) {
         *err = std::string("nb: kernel launch failed: ") + hipGetErrorString(e);

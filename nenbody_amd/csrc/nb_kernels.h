@@ -15,10 +15,11 @@ struct StepArgs {
     float dt, G, bias;     // main.rs:411-413
     uint32_t lo_bits, hi_bits;  // STRICT: bit patterns of the magnitude range where the unscaled divide ladder is exact
     uint32_t force_ieee;        // STRICT: 1 = always take the IEEE '/' path (parameters outside the proven range; tests)
+    uint32_t force_3d;          // 2 (= kFlagNonPlanar) = never take the planar (z == 0) shortcut (tests, measurements)
     uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
 };
 
-hipError_t launch_strict(const StepArgs &a, uint32_t tile, hipStream_t s);
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, hipStream_t s);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);

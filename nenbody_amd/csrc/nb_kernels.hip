@@ -52,11 +52,14 @@ __device__ __forceinline__ void tile_fetch(TileRegs<TJ> &t, const float4 *__rest
     }
 }
 
+// The LDS record is (x, y, z, bias): the softening constant rides in the unused w slot, so the fold reads
+// one ds_read_b128 per j (4 LDS cycles; a 12-byte read costs 8) and needs no separate operand for bias.
 template <int TJ>
-__device__ __forceinline__ void tile_store(const TileRegs<TJ> &t, float4 *lds_tile, int tid)
+__device__ __forceinline__ void tile_store(const TileRegs<TJ> &t, float4 *lds_tile, int tid, float bias)
 {
 #pragma unroll
-    for (int k = 0; k < TJ / kBlock; ++k) lds_tile[k * kBlock + tid] = t.r[k];
+    for (int k = 0; k < TJ / kBlock; ++k)
+        lds_tile[k * kBlock + tid] = make_float4(t.r[k].x, t.r[k].y, t.r[k].z, bias);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -87,53 +90,64 @@ __device__ __forceinline__ float div_ladder(float n, float d, float r)
     return __builtin_fmaf(t1, r, q1);
 }
 
-template <bool IEEE>
-__device__ __forceinline__ void pair_strict(const float4 pj, float xi, float yi, float zi, float G, float bias, float &qx,
-                                            float &qy, float &qz)
+// PLANAR: every z in the tile and every z of this workgroup's bodies is (+/-)0.  Then dz = 0, dz*dz = +0,
+// (xx + yy) + 0 == xx + yy, and the z term of the sum is +/-0, which leaves the running sum unchanged:
+// skipping the z arithmetic is exact, not an approximation (the reference's own initial state is planar,
+// main.rs:740, 745, and stays planar).
+template <bool IEEE, bool PLANAR>
+__device__ __forceinline__ void pair_strict(const float4 pj, float xi, float yi, float zi, float G, float &qx, float &qy,
+                                            float &qz)
 {
     // main.rs:428  vec = p_i - p_n   (the reference recomputes the same difference inside distance2)
-    const float dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi;
-    // main.rs:429  dist = ((dx*dx + dy*dy) + dz*dz) + bias
-    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-    const float d = ((xx + yy) + zz) + bias;
+    const float dx = pj.x - xi, dy = pj.y - yi;
+    const float xx = dx * dx, yy = dy * dy;
+    float d, dz = 0.f;
+    // main.rs:429  dist = ((dx*dx + dy*dy) + dz*dz) + bias          (pj.w holds bias)
+    if (PLANAR) {
+        d = (xx + yy) + pj.w;
+    } else {
+        dz = pj.z - zi;
+        const float zz = dz * dz;
+        d = ((xx + yy) + zz) + pj.w;
+    }
     // main.rs:430  (vec * G) / dist, component-wise
-    const float nx = dx * G, ny = dy * G, nz = dz * G;
+    const float nx = dx * G, ny = dy * G;
     if (IEEE) {
         qx = nx / d;
         qy = ny / d;
-        qz = nz / d;
+        qz = PLANAR ? 0.f : (dz * G) / d;
     } else {
         const float r0 = __builtin_amdgcn_rcpf(d);
         const float e = __builtin_fmaf(-d, r0, 1.0f);
         const float r = __builtin_fmaf(e, r0, r0);
         qx = div_ladder(nx, d, r);
         qy = div_ladder(ny, d, r);
-        qz = div_ladder(nz, d, r);
+        qz = PLANAR ? 0.f : div_ladder(dz * G, d, r);
     }
 }
 
-template <bool IEEE, int U>
+template <bool IEEE, bool PLANAR, int U>
 __device__ __forceinline__ void fold_tile_strict(const float4 *tile, int nj, float xi, float yi, float zi, float G,
-                                                 float bias, float &sx, float &sy, float &sz)
+                                                 float &sx, float &sy, float &sz)
 {
     int j = 0;
     for (; j + U <= nj; j += U) {
         float qx[U], qy[U], qz[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pair_strict<IEEE>(tile[j + u], xi, yi, zi, G, bias, qx[u], qy[u], qz[u]);
+        for (int u = 0; u < U; ++u) pair_strict<IEEE, PLANAR>(tile[j + u], xi, yi, zi, G, qx[u], qy[u], qz[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // main.rs:430  sum + term, strictly in index order
             sx = sx + qx[u];
             sy = sy + qy[u];
-            sz = sz + qz[u];
+            if (!PLANAR) sz = sz + qz[u];
         }
     }
     for (; j < nj; ++j) {
         float qx, qy, qz;
-        pair_strict<IEEE>(tile[j], xi, yi, zi, G, bias, qx, qy, qz);
+        pair_strict<IEEE, PLANAR>(tile[j], xi, yi, zi, G, qx, qy, qz);
         sx = sx + qx;
         sy = sy + qy;
-        sz = sz + qz;
+        if (!PLANAR) sz = sz + qz;
     }
 }
 
@@ -151,12 +165,22 @@ __device__ __forceinline__ void integrate(float4 &p, float4 &v, float ax, float 
     v.w = 0.f;
 }
 
-template <int TJ>
+constexpr uint32_t kFlagIeee = 1u;       // a coordinate outside the ladder's proven range -> IEEE '/' for the tile
+constexpr uint32_t kFlagNonPlanar = 2u;  // some z != 0
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    return (__any((int)(v & kFlagIeee)) ? kFlagIeee : 0u) | (__any((int)(v & kFlagNonPlanar)) ? kFlagNonPlanar : 0u);
+}
+
+__device__ __forceinline__ uint32_t nonzero_bits(float c) { return (__float_as_uint(c) & 0x7fffffffu) != 0u ? kFlagNonPlanar : 0u; }
+
+template <int TJ, int U>
 __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 {
     __shared__ float4 tile[2][TJ];
-    __shared__ uint32_t tile_bad[2][kWaves];
-    __shared__ uint32_t self_bad[kWaves];
+    __shared__ uint32_t tile_flags[2][kWaves];
+    __shared__ uint32_t self_flags[kWaves];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -168,9 +192,10 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 
     const uint32_t lo = a.lo_bits, span = a.hi_bits - a.lo_bits;
     {
-        const uint32_t bad = coord_oor(xi, lo, span) | coord_oor(yi, lo, span) | coord_oor(zi, lo, span) | a.force_ieee;
-        const uint32_t wbad = __any((int)bad) ? 1u : 0u;
-        if ((tid & 63) == 0) self_bad[wave] = wbad;
+        uint32_t f = coord_oor(xi, lo, span) | coord_oor(yi, lo, span) | coord_oor(zi, lo, span) | a.force_ieee;
+        f |= nonzero_bits(zi) | a.force_3d;
+        f = wave_or(f);
+        if ((tid & 63) == 0) self_flags[wave] = f;
     }
 
     TileRegs<TJ> regs;
@@ -178,30 +203,34 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
     const uint32_t ntiles = (n + (uint32_t)TJ - 1u) / (uint32_t)TJ;
     tile_fetch<TJ>(regs, a.pos_in, 0u, n, tid);
     auto publish = [&](int buf) {
-        uint32_t bad = 0;
+        uint32_t f = 0;
 #pragma unroll
-        for (int k = 0; k < TJ / kBlock; ++k)
-            bad |= coord_oor(regs.r[k].x, lo, span) | coord_oor(regs.r[k].y, lo, span) | coord_oor(regs.r[k].z, lo, span);
-        const uint32_t wbad = __any((int)bad) ? 1u : 0u;
-        tile_store<TJ>(regs, tile[buf], tid);
-        if ((tid & 63) == 0) tile_bad[buf][wave] = wbad;
+        for (int k = 0; k < TJ / kBlock; ++k) {
+            f |= coord_oor(regs.r[k].x, lo, span) | coord_oor(regs.r[k].y, lo, span) | coord_oor(regs.r[k].z, lo, span);
+            f |= nonzero_bits(regs.r[k].z);
+        }
+        f = wave_or(f);
+        tile_store<TJ>(regs, tile[buf], tid, a.bias);
+        if ((tid & 63) == 0) tile_flags[buf][wave] = f;
     };
     publish(0);
     __syncthreads();
-    const uint32_t block_self_bad = self_bad[0] | self_bad[1] | self_bad[2] | self_bad[3];
+    const uint32_t block_self = self_flags[0] | self_flags[1] | self_flags[2] | self_flags[3];
 
     float sx = 0.f, sy = 0.f, sz = 0.f;  // main.rs:426  Vector3::new(0.0, 0.0, 0.0)
     int buf = 0;
     for (uint32_t t = 0; t < ntiles; ++t) {
         const bool more = (t + 1u) < ntiles;
         if (more) tile_fetch<TJ>(regs, a.pos_in, (t + 1u) * (uint32_t)TJ, n, tid);
-        const uint32_t ieee = block_self_bad | tile_bad[buf][0] | tile_bad[buf][1] | tile_bad[buf][2] | tile_bad[buf][3];
+        const uint32_t f = block_self | tile_flags[buf][0] | tile_flags[buf][1] | tile_flags[buf][2] | tile_flags[buf][3];
         const uint32_t left = n - t * (uint32_t)TJ;
         const int nj = left < (uint32_t)TJ ? (int)left : TJ;
-        if (ieee == 0u)
-            fold_tile_strict<false, 4>(tile[buf], nj, xi, yi, zi, a.G, a.bias, sx, sy, sz);
+        if (f == 0u)
+            fold_tile_strict<false, true, U>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
+        else if ((f & kFlagIeee) == 0u)
+            fold_tile_strict<false, false, U>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
         else
-            fold_tile_strict<true, 2>(tile[buf], nj, xi, yi, zi, a.G, a.bias, sx, sy, sz);
+            fold_tile_strict<true, false, 2>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
         if (more) publish(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -219,22 +248,25 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 // ------------------------------------------------------------------------------------------------
 // FAST arithmetic
 // ------------------------------------------------------------------------------------------------
-template <int IB, int U>
+template <int IB, int U, bool PLANAR>
 __device__ __forceinline__ void fold_tile_fast(const float4 *tile, int nj, const float (&xi)[IB], const float (&yi)[IB],
-                                               const float (&zi)[IB], float bias, float (&ax)[IB], float (&ay)[IB],
-                                               float (&az)[IB])
+                                               const float (&zi)[IB], float (&ax)[IB], float (&ay)[IB], float (&az)[IB])
 {
     auto pair = [&](const float4 pj) {
 #pragma unroll
         for (int b = 0; b < IB; ++b) {
-            const float dx = pj.x - xi[b], dy = pj.y - yi[b], dz = pj.z - zi[b];
-            float r2 = __builtin_fmaf(dx, dx, bias);
+            const float dx = pj.x - xi[b], dy = pj.y - yi[b];
+            float r2 = __builtin_fmaf(dx, dx, pj.w);  // pj.w holds bias
             r2 = __builtin_fmaf(dy, dy, r2);
-            r2 = __builtin_fmaf(dz, dz, r2);
+            float dz = 0.f;
+            if (!PLANAR) {
+                dz = pj.z - zi[b];
+                r2 = __builtin_fmaf(dz, dz, r2);
+            }
             const float inv = __builtin_amdgcn_rcpf(r2);
             ax[b] = __builtin_fmaf(dx, inv, ax[b]);
             ay[b] = __builtin_fmaf(dy, inv, ay[b]);
-            az[b] = __builtin_fmaf(dz, inv, az[b]);
+            if (!PLANAR) az[b] = __builtin_fmaf(dz, inv, az[b]);
         }
     };
     int j = 0;
@@ -252,10 +284,14 @@ template <int TJ, int IB>
 __global__ __launch_bounds__(kBlock) void step_fast_kernel(StepArgs a)
 {
     __shared__ float4 tile[2][TJ];
+    __shared__ uint32_t tile_flags[2][kWaves];
+    __shared__ uint32_t self_flags[kWaves];
 
     const int tid = threadIdx.x;
+    const int wave = tid >> 6;
     const uint32_t base = blockIdx.x * (uint32_t)(kBlock * IB) + (uint32_t)tid;
     float xi[IB], yi[IB], zi[IB], ax[IB], ay[IB], az[IB];
+    uint32_t sf = a.force_3d;
 #pragma unroll
     for (int b = 0; b < IB; ++b) {
         const uint32_t l = base + (uint32_t)(b * kBlock);
@@ -264,7 +300,10 @@ __global__ __launch_bounds__(kBlock) void step_fast_kernel(StepArgs a)
         yi[b] = p.y;
         zi[b] = p.z;
         ax[b] = ay[b] = az[b] = 0.f;
+        sf |= nonzero_bits(p.z);
     }
+    sf = wave_or(sf);
+    if ((tid & 63) == 0) self_flags[wave] = sf;
 
     const uint32_t j_lo = blockIdx.y * a.j_chunk;
     const uint32_t j_hi = (j_lo + a.j_chunk < a.n_total) ? j_lo + a.j_chunk : a.n_total;
@@ -272,19 +311,32 @@ __global__ __launch_bounds__(kBlock) void step_fast_kernel(StepArgs a)
     const uint32_t ntiles = (span + (uint32_t)TJ - 1u) / (uint32_t)TJ;
 
     TileRegs<TJ> regs;
+    auto publish = [&](int buf) {
+        uint32_t f = 0;
+#pragma unroll
+        for (int k = 0; k < TJ / kBlock; ++k) f |= nonzero_bits(regs.r[k].z);
+        f = wave_or(f);
+        tile_store<TJ>(regs, tile[buf], tid, a.bias);
+        if ((tid & 63) == 0) tile_flags[buf][wave] = f;
+    };
     if (ntiles) {
         tile_fetch<TJ>(regs, a.pos_in, j_lo, j_hi, tid);
-        tile_store<TJ>(regs, tile[0], tid);
+        publish(0);
     }
     __syncthreads();
+    const uint32_t block_self = self_flags[0] | self_flags[1] | self_flags[2] | self_flags[3];
     int buf = 0;
     for (uint32_t t = 0; t < ntiles; ++t) {
         const bool more = (t + 1u) < ntiles;
         if (more) tile_fetch<TJ>(regs, a.pos_in, j_lo + (t + 1u) * (uint32_t)TJ, j_hi, tid);
         const uint32_t left = span - t * (uint32_t)TJ;
         const int nj = left < (uint32_t)TJ ? (int)left : TJ;
-        fold_tile_fast<IB, 8 / IB>(tile[buf], nj, xi, yi, zi, a.bias, ax, ay, az);
-        if (more) tile_store<TJ>(regs, tile[buf ^ 1], tid);
+        const uint32_t f = block_self | tile_flags[buf][0] | tile_flags[buf][1] | tile_flags[buf][2] | tile_flags[buf][3];
+        if (f == 0u)
+            fold_tile_fast<IB, 8 / IB, true>(tile[buf], nj, xi, yi, zi, ax, ay, az);
+        else
+            fold_tile_fast<IB, 8 / IB, false>(tile[buf], nj, xi, yi, zi, ax, ay, az);
+        if (more) publish(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -378,21 +430,25 @@ __global__ __launch_bounds__(kBlock) void unpack_kernel(uint32_t count, const fl
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
-template <int TJ>
+template <int TJ, int U>
 static hipError_t launch_strict_t(const StepArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(step_strict_kernel<TJ>, dim3(ceil_div(a.count, kBlock)), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((step_strict_kernel<TJ, U>), dim3(ceil_div(a.count, kBlock)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_strict(const StepArgs &a, uint32_t tile, hipStream_t s)
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, hipStream_t s)
 {
-    switch (tile) {
-        case 256: return launch_strict_t<256>(a, s);
-        case 512: return launch_strict_t<512>(a, s);
-        case 1024: return launch_strict_t<1024>(a, s);
-        default: return hipErrorInvalidValue;
-    }
+#define NBK_CASE(T, U_) \
+    if (tile == T && unroll == U_) return launch_strict_t<T, U_>(a, s)
+    NBK_CASE(256, 4);
+    NBK_CASE(256, 8);
+    NBK_CASE(512, 4);
+    NBK_CASE(512, 8);
+    NBK_CASE(1024, 4);
+    NBK_CASE(1024, 8);
+#undef NBK_CASE
+    return hipErrorInvalidValue;
 }
 
 template <int TJ, int IB>

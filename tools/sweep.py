@@ -31,9 +31,64 @@ def run(n, mode, steps, env):
           f"TF18={pairs * 18 / 1e12:6.1f} ({pairs * 18 / 157.3e12 * 100:4.1f}%)", flush=True)
 
 
+def shard_sweep(n_total=131072):
+    """Kernel-only time of one rank's share at world sizes 1..8 (what bounds multi-GPU strong scaling)."""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    be = HipBackend()
+    dev = torch.device("cuda", 0)
+    pos, vel = nb.init_state(n_total, 1234)
+    cur = torch.zeros((n_total, 4)); cur[:, :3] = torch.from_numpy(pos); cur = cur.to(dev)
+    nxt = torch.zeros_like(cur)
+    for mode in (nb.NB_MODE_STRICT, nb.NB_MODE_FAST):
+        for env in ({}, {"NB_FORCE_3D": 1}):
+            for k, v in env.items():
+                os.environ[k] = str(v)
+            base = None
+            for world in (1, 2, 4, 8):
+                count = n_total // world
+                params = nb.default_params(mode=mode)
+                v4 = torch.zeros((count, 4), device=dev)
+                sb = be.scratch_bytes(params, n_total, count)
+                scratch = torch.empty((sb,), dtype=torch.uint8, device=dev) if sb else None
+                for _ in range(2):
+                    be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
+                torch.cuda.synchronize()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                base = base or dt
+                print(f"shard mode={'strict' if mode == 0 else 'fast'} {env} world={world} count={count:7d} ms={dt * 1e3:8.3f} "
+                      f"compute-only speedup={base / dt:5.2f}", flush=True)
+            for k in env:
+                os.environ.pop(k, None)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "strict"
-    if what == "strict":
+    if what == "shard":
+        return shard_sweep()
+    if what == "strict2":
+        for env in ({}, {"NB_FORCE_3D": 1}, {"NB_STRICT_UNROLL": 8}, {"NB_FORCE_3D": 1, "NB_STRICT_UNROLL": 8},
+                    {"NB_TILE": 1024}, {"NB_TILE": 1024, "NB_STRICT_UNROLL": 8}):
+            run(131072, nb.NB_MODE_STRICT, 5, env)
+        run(524288, nb.NB_MODE_STRICT, 2, {})
+        run(524288, nb.NB_MODE_STRICT, 2, {"NB_FORCE_3D": 1})
+    elif what == "fast2":
+        for env in ({"NB_FAST_IB": 1, "NB_FAST_SLICES": 16, "NB_TILE": 1024}, {"NB_FAST_IB": 2, "NB_FAST_SLICES": 16, "NB_TILE": 1024},
+                    {"NB_FAST_IB": 2, "NB_FAST_SLICES": 16, "NB_TILE": 1024, "NB_FORCE_3D": 1},
+                    {"NB_FAST_IB": 2, "NB_FAST_SLICES": 32, "NB_TILE": 512}, {"NB_FAST_IB": 4, "NB_FAST_SLICES": 32, "NB_TILE": 512},
+                    {"NB_FAST_IB": 1, "NB_FAST_SLICES": 32, "NB_TILE": 512, "NB_FORCE_3D": 1}, {}):
+            run(131072, nb.NB_MODE_FAST, 10, env)
+        for env in ({"NB_FAST_IB": 1, "NB_FAST_SLICES": 64, "NB_TILE": 256}, {"NB_FAST_IB": 1, "NB_FAST_SLICES": 32, "NB_TILE": 512},
+                    {"NB_FAST_IB": 2, "NB_FAST_SLICES": 64, "NB_TILE": 256}, {}):
+            run(16384, nb.NB_MODE_FAST, 20, env)
+    elif what == "strict":
         for n in (32768, 65536, 131072, 262144, 524288):
             for tile in (256, 512, 1024):
                 run(n, nb.NB_MODE_STRICT, max(2, min(10, int(2e11 / (n * n)))), {"NB_TILE": tile})
