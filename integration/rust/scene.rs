@@ -1,0 +1,153 @@
+//! src/scene.rs -- fills the reference's empty module (reference src/scene.rs:1, `mod scene;` at src/main.rs:2).
+//!
+//! A `Scene` owns the simulation state the reference keeps as locals of `main()` (src/main.rs:738-750) and
+//! advances it with libnenbody_hip.so (include/nenbody.h).  `Scene::step()` is `update_instance_nbody`
+//! (src/main.rs:404-441) on the GPU; afterwards `positions`, `velocities` and `instances` hold what the
+//! per-frame consumers read (src/main.rs:932-945).
+//!
+//! NOT COMPILED in the build environment (no cargo/rustc there): a mechanical binding of the C ABI.
+use cgmath::{Point3, Vector3};
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct NbParams {
+    pub dt: f32,   // src/main.rs:411
+    pub g: f32,    // src/main.rs:412
+    pub bias: f32, // src/main.rs:413
+    pub tile: u32, // 0 = library default
+    pub mode: u32, // 0 = STRICT (bit-identical to the CPU path), 1 = FAST
+}
+
+#[repr(C)]
+pub struct NbCtx {
+    _private: [u8; 0],
+}
+
+#[link(name = "nenbody_hip")]
+extern "C" {
+    fn nb_default_params(p: *mut NbParams);
+    fn nb_last_error(ctx: *const NbCtx) -> *const c_char;
+    fn nb_init_state(seed: u64, n: u32, pos_xyz: *mut f32, vel_xyz: *mut f32) -> c_int;
+    fn nb_create(n: u32, n_devices: u32, params: *const NbParams, out: *mut *mut NbCtx) -> c_int;
+    fn nb_destroy(ctx: *mut NbCtx);
+    fn nb_upload(ctx: *mut NbCtx, pos_xyz: *const f32, vel_xyz: *const f32) -> c_int;
+    fn nb_step(ctx: *mut NbCtx, k: u32) -> c_int;
+    fn nb_download(ctx: *mut NbCtx, pos_xyz: *mut f32, vel_xyz: *mut f32, inst_16n: *mut f32) -> c_int;
+    fn nb_sync(ctx: *mut NbCtx) -> c_int;
+}
+
+impl Default for NbParams {
+    fn default() -> Self {
+        let mut p = NbParams { dt: 0.0, g: 0.0, bias: 0.0, tile: 0, mode: 0 };
+        unsafe { nb_default_params(&mut p) };
+        p
+    }
+}
+
+#[derive(Debug)]
+pub struct SceneError(pub i32, pub String);
+
+fn check(rc: c_int, ctx: *const NbCtx) -> Result<(), SceneError> {
+    if rc == 0 {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(nb_last_error(ctx)) }.to_string_lossy().into_owned();
+    Err(SceneError(rc, msg))
+}
+
+/// Single owner of a device context: `Send`, not `Sync` (the reference calls the update on the winit main
+/// thread, src/main.rs:925).
+pub struct Scene {
+    ctx: *mut NbCtx,
+    pub positions: Vec<Point3<f32>>,   // src/main.rs:743
+    pub velocities: Vec<Vector3<f32>>, // src/main.rs:738
+    pub instances: Vec<[[f32; 4]; 4]>, // instance_data, uploaded at src/main.rs:932-936
+}
+
+unsafe impl Send for Scene {}
+
+impl Scene {
+    /// `entity_count` bodies with the reference's initial distributions (src/main.rs:738-747), seeded.
+    pub fn new(n: usize, params: NbParams, seed: u64) -> Result<Scene, SceneError> {
+        let mut positions = vec![Point3::new(0.0f32, 0.0, 0.0); n];
+        let mut velocities = vec![Vector3::new(0.0f32, 0.0, 0.0); n];
+        // Point3<f32> / Vector3<f32> are #[repr(C)] {x, y, z}: the Vec's buffer is the stride-3 array the ABI takes
+        check(
+            unsafe { nb_init_state(seed, n as u32, positions.as_mut_ptr() as *mut f32, velocities.as_mut_ptr() as *mut f32) },
+            std::ptr::null(),
+        )?;
+        Scene::from_state(positions, velocities, params)
+    }
+
+    pub fn from_state(positions: Vec<Point3<f32>>, velocities: Vec<Vector3<f32>>, params: NbParams) -> Result<Scene, SceneError> {
+        // same panic the reference has at src/main.rs:415-416 (copy_from_slice on unequal lengths)
+        assert_eq!(positions.len(), velocities.len(), "positions and velocities must have the same length");
+        let n = positions.len();
+        let mut ctx: *mut NbCtx = std::ptr::null_mut();
+        check(unsafe { nb_create(n as u32, 1, &params, &mut ctx) }, std::ptr::null())?;
+        let scene = Scene { ctx, positions, velocities, instances: vec![[[0.0; 4]; 4]; n] };
+        check(
+            unsafe { nb_upload(scene.ctx, scene.positions.as_ptr() as *const f32, scene.velocities.as_ptr() as *const f32) },
+            scene.ctx,
+        )?;
+        Ok(scene)
+    }
+
+    /// One `update_instance_nbody` (src/main.rs:404-441); host mirrors refreshed so the consumers at
+    /// src/main.rs:932-945 work unchanged.
+    pub fn step(&mut self) -> Result<(), SceneError> {
+        check(unsafe { nb_step(self.ctx, 1) }, self.ctx)?;
+        check(
+            unsafe {
+                nb_download(
+                    self.ctx,
+                    self.positions.as_mut_ptr() as *mut f32,
+                    self.velocities.as_mut_ptr() as *mut f32,
+                    self.instances.as_mut_ptr() as *mut f32,
+                )
+            },
+            self.ctx,
+        )
+    }
+
+    /// k steps, device-resident, no download: the benchmark path.
+    pub fn step_n(&mut self, k: u32) -> Result<(), SceneError> {
+        check(unsafe { nb_step(self.ctx, k) }, self.ctx)
+    }
+
+    pub fn sync(&mut self) -> Result<(), SceneError> {
+        check(unsafe { nb_sync(self.ctx) }, self.ctx)
+    }
+}
+
+impl Drop for Scene {
+    fn drop(&mut self) {
+        unsafe { nb_destroy(self.ctx) };
+    }
+}
+
+/// Drop-in for the reference's free function (same five arguments, src/main.rs:404-410): one upload, one step,
+/// one download per call.  A caller that steps every frame should hold a `Scene` instead.
+pub fn update_instance_nbody(
+    instances: &mut Vec<[[f32; 4]; 4]>,
+    positions: &mut Vec<Point3<f32>>,
+    old_positions: &mut Vec<Point3<f32>>,
+    velocities: &mut Vec<Vector3<f32>>,
+    old_velocities: &mut Vec<Vector3<f32>>,
+) {
+    old_positions.copy_from_slice(positions.as_slice()); // src/main.rs:415 (panics on a length mismatch)
+    old_velocities.copy_from_slice(velocities.as_slice()); // src/main.rs:416
+    let count = instances.len().min(positions.len()).min(velocities.len()); // zip, src/main.rs:420-423
+    if count == 0 {
+        return;
+    }
+    let mut vel_full = velocities.clone();
+    vel_full.resize(positions.len(), Vector3::new(0.0, 0.0, 0.0)); // bodies past the zip are computed and dropped
+    let mut scene = Scene::from_state(old_positions.clone(), vel_full, NbParams::default()).expect("nenbody_hip");
+    scene.step().expect("nenbody_hip step");
+    positions[..count].copy_from_slice(&scene.positions[..count]);
+    velocities[..count].copy_from_slice(&scene.velocities[..count]);
+    instances[..count].copy_from_slice(&scene.instances[..count]);
+}
