@@ -41,7 +41,8 @@ struct Plan {
     uint32_t j_chunk;
     uint32_t lo_bits, hi_bits, force_ieee;  // STRICT guard
     uint32_t force_3d;                      // 2 = never take the planar shortcut (NB_FORCE_3D=1: tests, measurements)
-    uint32_t unroll;                        // STRICT: pairs in flight per lane (4 or 8)
+    uint32_t unroll;                        // STRICT: pairs in flight per lane (2, 4 or 8)
+    uint32_t lanes;                         // STRICT: lanes per body (1 = plain; 2..16 = j-parallel, same summation order)
 };
 
 int floor_log2f(float x)
@@ -65,7 +66,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     Plan pl{};
     pl.tile = p.tile;
     if (pl.tile == 0) {
-        pl.tile = (p.mode == NB_MODE_STRICT) ? 256u : 512u;
+        pl.tile = (p.mode == NB_MODE_STRICT) ? 1024u : 512u;
         env_u32("NB_TILE", &pl.tile);
     }
     if (!valid_tile(pl.tile)) {
@@ -117,9 +118,22 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
     f = 0;
     pl.force_3d = (env_u32("NB_FORCE_3D", &f) && f) ? 2u : 0u;
-    pl.unroll = 4;
+    // STRICT cannot split the fold over j (the sum is sequential), so a small shard would leave SIMDs idle:
+    // below 65 536 bodies give each body S lanes until the shard supplies 2 waves per SIMD (256 CUs x 4 SIMDs x 2 =
+    // 2048 waves).  The DPP adds of the j-parallel form cost about twice a plain add, so S = 1 stays ahead down to
+    // one wave per SIMD (measured: profiles/r01_jp/sweep_lanes.log).
+    pl.lanes = 1;
+    if (count < 65536u)
+        while (pl.lanes < 16 && (uint64_t)count * pl.lanes < 2048ull * 64ull) pl.lanes *= 2;
+    env_u32("NB_STRICT_LANES", &pl.lanes);
+    if (pl.lanes != 1 && pl.lanes != 2 && pl.lanes != 4 && pl.lanes != 8 && pl.lanes != 16) pl.lanes = 1;
+    pl.unroll = pl.lanes == 1 ? 8 : (pl.lanes == 16 ? 2 : 4);
     env_u32("NB_STRICT_UNROLL", &pl.unroll);
-    if (pl.unroll != 4 && pl.unroll != 8) pl.unroll = 4;
+    if (pl.lanes == 1 && pl.unroll != 4 && pl.unroll != 8) pl.unroll = 8;
+    if (pl.lanes > 1 && pl.unroll != 2 && pl.unroll != 4) pl.unroll = 4;
+    if (pl.lanes == 16) pl.unroll = 2;
+    if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 512) pl.tile = 1024;  // built j-parallel shapes: 256, 1024
+    if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 1024 && pl.unroll == 2 && pl.lanes < 8) pl.unroll = 4;
     *out = pl;
     return NB_OK;
 }
@@ -148,7 +162,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.force_ieee = pl.force_ieee;
     a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
-    hipError_t e = (p.mode == NB_MODE_STRICT) ? nbk::launch_strict(a, pl.tile, pl.unroll, stream)
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream)
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
     if (e != hipSuccess) {
         *err = std::string("nb: kernel launch failed: ") + hipGetErrorString(e);

@@ -19,7 +19,8 @@ struct StepArgs {
     uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
 };
 
-hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, hipStream_t s);
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
+hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_JP_TU
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);

@@ -126,28 +126,67 @@ __device__ __forceinline__ void pair_strict(const float4 pj, float xi, float yi,
     }
 }
 
-template <bool IEEE, bool PLANAR, int U>
-__device__ __forceinline__ void fold_tile_strict(const float4 *tile, int nj, float xi, float yi, float zi, float G,
+// q of the lane SP places to the right (lane + SP) within a 16-lane DPP row: row_shl:SP.  With all masks enabled and
+// bound_ctrl the mov folds into the consuming add (v_add_f32_dpp), so fetching a neighbour's quotient costs no
+// instruction of its own and no LDS traffic.
+template <int SP>
+__device__ __forceinline__ float lane_right(float v)
+{
+    static_assert(SP >= 1 && SP <= 15, "row_shl:1..15");
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + SP, 0xf, 0xf, true));
+}
+
+// sum += q of the body's lane 0, then lane 1, ... lane S-1: the index order of the S j's of a group.  Only the
+// FIRST lane of each S-lane group ends up with the body's true running sum (it sees lanes +0..+S-1, all inside its
+// group and its DPP row since S <= 16 and groups are S-aligned); the other lanes compute values nobody reads.
+template <int S, int SP = 0>
+__device__ __forceinline__ void add_in_lane_order(float &sum, float q)
+{
+    if constexpr (SP == 0) {
+        sum = sum + q;
+    } else {
+        sum = sum + lane_right<SP>(q);
+    }
+    if constexpr (SP + 1 < S) add_in_lane_order<S, SP + 1>(sum, q);
+}
+
+// The fold over one LDS tile, main.rs:425-432.  S = 1: one lane per body walks j in order.  S > 1 ("j-parallel"):
+// the S lanes of a body evaluate the S pairs j = g+0 .. g+S-1 of a group concurrently, then the body's first lane
+// adds the S quotients in index order (add_in_lane_order), so its running sum sees exactly the reference's sequence
+// of additions.  The summation order is untouched; only the independent per-pair work is spread over lanes.
+template <bool IEEE, bool PLANAR, int U, int S>
+__device__ __forceinline__ void fold_tile_strict(const float4 *tile, int nj, int sl, float xi, float yi, float zi, float G,
                                                  float &sx, float &sy, float &sz)
 {
-    int j = 0;
-    for (; j + U <= nj; j += U) {
+    int g = 0;
+    for (; g + U * S <= nj; g += U * S) {
         float qx[U], qy[U], qz[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pair_strict<IEEE, PLANAR>(tile[j + u], xi, yi, zi, G, qx[u], qy[u], qz[u]);
+        for (int u = 0; u < U; ++u) pair_strict<IEEE, PLANAR>(tile[g + u * S + sl], xi, yi, zi, G, qx[u], qy[u], qz[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // main.rs:430  sum + term, strictly in index order
-            sx = sx + qx[u];
-            sy = sy + qy[u];
-            if (!PLANAR) sz = sz + qz[u];
+            add_in_lane_order<S>(sx, qx[u]);
+            add_in_lane_order<S>(sy, qy[u]);
+            if (!PLANAR) add_in_lane_order<S>(sz, qz[u]);
         }
     }
-    for (; j < nj; ++j) {
+    for (; g + S <= nj; g += S) {
         float qx, qy, qz;
-        pair_strict<IEEE, PLANAR>(tile[j], xi, yi, zi, G, qx, qy, qz);
-        sx = sx + qx;
-        sy = sy + qy;
-        if (!PLANAR) sz = sz + qz;
+        pair_strict<IEEE, PLANAR>(tile[g + sl], xi, yi, zi, G, qx, qy, qz);
+        add_in_lane_order<S>(sx, qx);
+        add_in_lane_order<S>(sy, qy);
+        if (!PLANAR) add_in_lane_order<S>(sz, qz);
+    }
+    if (S > 1 && g < nj) {  // last, partial group of the whole set: lanes past the end contribute +0 (x + 0 == x)
+        const bool valid = g + sl < nj;
+        float qx, qy, qz;
+        pair_strict<IEEE, PLANAR>(tile[valid ? g + sl : g], xi, yi, zi, G, qx, qy, qz);
+        qx = valid ? qx : 0.f;
+        qy = valid ? qy : 0.f;
+        qz = valid ? qz : 0.f;
+        add_in_lane_order<S>(sx, qx);
+        add_in_lane_order<S>(sy, qy);
+        if (!PLANAR) add_in_lane_order<S>(sz, qz);
     }
 }
 
@@ -175,7 +214,9 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 
 __device__ __forceinline__ uint32_t nonzero_bits(float c) { return (__float_as_uint(c) & 0x7fffffffu) != 0u ? kFlagNonPlanar : 0u; }
 
-template <int TJ, int U>
+// S lanes per body (1, 2, 4, 8, 16): a workgroup covers 256/S bodies.  S > 1 multiplies the wave count of a
+// shard by S without touching the summation order: that is what lets STRICT fill the chip when a rank owns few bodies.
+template <int TJ, int U, int S>
 __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 {
     __shared__ float4 tile[2][TJ];
@@ -184,7 +225,8 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    const uint32_t l = blockIdx.x * (uint32_t)kBlock + (uint32_t)tid;  // index inside the shard
+    const int sl = tid & (S - 1);                                                       // which of the body's S lanes
+    const uint32_t l = blockIdx.x * (uint32_t)(kBlock / S) + (uint32_t)(tid / S);      // body index inside the shard
     const bool live = l < a.count;
     const uint32_t gi = a.first + (live ? l : a.count - 1u);
     const float4 pi = a.pos_in[gi];
@@ -226,17 +268,17 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
         const uint32_t left = n - t * (uint32_t)TJ;
         const int nj = left < (uint32_t)TJ ? (int)left : TJ;
         if (f == 0u)
-            fold_tile_strict<false, true, U>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
+            fold_tile_strict<false, true, U, S>(tile[buf], nj, sl, xi, yi, zi, a.G, sx, sy, sz);
         else if ((f & kFlagIeee) == 0u)
-            fold_tile_strict<false, false, U>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
+            fold_tile_strict<false, false, U, S>(tile[buf], nj, sl, xi, yi, zi, a.G, sx, sy, sz);
         else
-            fold_tile_strict<true, false, 2>(tile[buf], nj, xi, yi, zi, a.G, sx, sy, sz);
+            fold_tile_strict<true, false, (S == 1 ? 2 : 1), S>(tile[buf], nj, sl, xi, yi, zi, a.G, sx, sy, sz);
         if (more) publish(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    if (live) {
+    if (live && sl == 0) {
         float4 p = pi;
         float4 v = a.vel[l];
         integrate(p, v, sx, sy, sz, a.dt);
@@ -245,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
     }
 }
 
+#ifndef NBK_JP_TU
 // ------------------------------------------------------------------------------------------------
 // FAST arithmetic
 // ------------------------------------------------------------------------------------------------
@@ -425,32 +468,61 @@ __global__ __launch_bounds__(kBlock) void unpack_kernel(uint32_t count, const fl
     xyz[3 * (size_t)l + 2] = r.z;
 }
 
+#endif  // !NBK_JP_TU
+
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
-template <int TJ, int U>
+template <int TJ, int U, int S>
 static hipError_t launch_strict_t(const StepArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL((step_strict_kernel<TJ, U>), dim3(ceil_div(a.count, kBlock)), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((step_strict_kernel<TJ, U, S>), dim3(ceil_div(a.count, kBlock / S)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, hipStream_t s)
+#define NBK_CASE(T, U_, S_) \
+    if (tile == T && unroll == U_ && lanes == S_) return launch_strict_t<T, U_, S_>(a, s)
+
+#ifdef NBK_JP_TU
+// This translation unit is the same source compiled with -DNBK_JP_TU -fno-slp-vectorize: it holds only the
+// j-parallel STRICT shapes (S > 1).  Without SLP the x/y running-sum adds stay scalar v_add_f32, so the row_shl DPP
+// fetch folds into them (v_add_f32_dpp); packed v_pk_add_f32 cannot take a DPP operand and would need a mov per term.
+hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s)
 {
-#define NBK_CASE(T, U_) \
-    if (tile == T && unroll == U_) return launch_strict_t<T, U_>(a, s)
-    NBK_CASE(256, 4);
-    NBK_CASE(256, 8);
-    NBK_CASE(512, 4);
-    NBK_CASE(512, 8);
-    NBK_CASE(1024, 4);
-    NBK_CASE(1024, 8);
-#undef NBK_CASE
+    // unroll counts groups of S pairs in flight
+    NBK_CASE(256, 4, 2);
+    NBK_CASE(256, 2, 2);
+    NBK_CASE(256, 4, 4);
+    NBK_CASE(256, 2, 4);
+    NBK_CASE(256, 4, 8);
+    NBK_CASE(256, 2, 8);
+    NBK_CASE(256, 4, 16);
+    NBK_CASE(256, 2, 16);
+    NBK_CASE(1024, 4, 2);
+    NBK_CASE(1024, 4, 4);
+    NBK_CASE(1024, 4, 8);
+    NBK_CASE(1024, 2, 8);
+    NBK_CASE(1024, 2, 16);
     return hipErrorInvalidValue;
 }
+#else
+hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s)
+{
+    if (lanes > 1) return launch_strict_jp(a, tile, unroll, lanes, s);
+    NBK_CASE(256, 4, 1);
+    NBK_CASE(256, 8, 1);
+    NBK_CASE(512, 4, 1);
+    NBK_CASE(512, 8, 1);
+    NBK_CASE(1024, 4, 1);
+    NBK_CASE(1024, 8, 1);
+    return hipErrorInvalidValue;
+}
+#endif
+#undef NBK_CASE
 
+#ifndef NBK_JP_TU
 template <int TJ, int IB>
 static hipError_t launch_fast_t(const StepArgs &a, uint32_t slices, hipStream_t s)
 {
@@ -495,5 +567,7 @@ hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStrea
     hipLaunchKernelGGL(unpack_kernel, dim3(ceil_div(count, kBlock)), dim3(kBlock), 0, s, count, rec, xyz);
     return hipGetLastError();
 }
+
+#endif  // !NBK_JP_TU
 
 }  // namespace nbk

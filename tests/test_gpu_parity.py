@@ -40,8 +40,16 @@ def state3d(oracle, n, seed):
 # ---------------------------------------------------------------------------------------------------------
 # STRICT: bit-exact
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 1025, 2049])
-def test_strict_ragged_sizes_bit_exact(nb, oracle, n):
+@pytest.fixture(params=[1, 2, 4, 8, 16], ids=lambda s: f"lanes{s}")
+def lanes(request, monkeypatch):
+    """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel with the same summation order).
+    By default the library picks it from the shard size; the tests pin every value."""
+    monkeypatch.setenv("NB_STRICT_LANES", str(request.param))
+    return request.param
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 17, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 1025, 2049])
+def test_strict_ragged_sizes_bit_exact(nb, oracle, lanes, n):
     pos, vel = state3d(oracle, n, seed=n)
     with nb.Scene(pos, vel) as sc:
         sc.step_n(3)
@@ -49,6 +57,45 @@ def test_strict_ragged_sizes_bit_exact(nb, oracle, n):
     p_ref, v_ref = oracle.run(pos, vel, 3)
     assert_bits_equal(p, p_ref, f"positions n={n}")
     assert_bits_equal(v, v_ref, f"velocities n={n}")
+
+
+@pytest.mark.parametrize("n", [5, 300, 1026])
+def test_strict_planar_ragged_sizes_bit_exact(nb, oracle, lanes, n):
+    """z = 0, vz = 0 (the reference's own initial state): the planar shortcut must not change a bit."""
+    pos, vel = oracle.init_state(n, seed=n + 1)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(4)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 4)
+    assert_bits_equal(p, p_ref, f"positions n={n}")
+    assert_bits_equal(v, v_ref, f"velocities n={n}")
+
+
+def test_strict_mixed_planar_and_3d_tiles_bit_exact(nb, oracle, lanes):
+    """Only some tiles are planar: z != 0 for bodies 600..899 only, and the workgroups owning them."""
+    n = 2500
+    pos, vel = oracle.init_state(n, seed=123)
+    pos[600:900, 2] = np.linspace(-5, 5, 300, dtype=np.float32)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(3)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 3)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_force_3d_switch_gives_the_same_bits(nb, oracle, monkeypatch):
+    pos, vel = oracle.init_state(3000, seed=7)
+    outs = []
+    for f3d in ("0", "1"):
+        monkeypatch.setenv("NB_FORCE_3D", f3d)
+        for mode in (nb.NB_MODE_STRICT, nb.NB_MODE_FAST):
+            with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
+                sc.step_n(3)
+                outs.append(sc.state())
+    assert_bits_equal(outs[0][0], outs[2][0], "STRICT planar vs 3-D path")
+    assert_bits_equal(outs[1][0], outs[3][0], "FAST planar vs 3-D path")
+    assert_bits_equal(outs[1][1], outs[3][1], "FAST planar vs 3-D path (vel)")
 
 
 @pytest.mark.parametrize("tile", [256, 512, 1024])
@@ -62,7 +109,10 @@ def test_strict_every_tile_size_bit_exact(nb, oracle, tile):
     assert_bits_equal(v, v_ref)
 
 
-def test_strict_golden_n16_and_n1024(nb):
+@pytest.mark.parametrize("force_lanes", [None, 1, 4])
+def test_strict_golden_n16_and_n1024(nb, monkeypatch, force_lanes):
+    if force_lanes is not None:
+        monkeypatch.setenv("NB_STRICT_LANES", str(force_lanes))
     g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden.npz"))
     seed = int(g["seed"][0])
     pos, vel = nb.init_state(16, seed)
@@ -102,7 +152,7 @@ def test_strict_config2_n16384_vs_oracle_and_golden(nb, oracle):
     assert_bits_equal(v, v_ref)
 
 
-def test_strict_ieee_fallback_path_bit_exact(nb, oracle, monkeypatch):
+def test_strict_ieee_fallback_path_bit_exact(nb, oracle, lanes, monkeypatch):
     """The guarded '/' path (taken when coordinates leave the range where the shared-reciprocal ladder is
     proven exact) must give the same bits; force it for every tile."""
     pos, vel = state3d(oracle, 1500, seed=77)
@@ -115,7 +165,7 @@ def test_strict_ieee_fallback_path_bit_exact(nb, oracle, monkeypatch):
     assert_bits_equal(v, v_ref)
 
 
-def test_strict_extreme_coordinates_bit_exact(nb, oracle):
+def test_strict_extreme_coordinates_bit_exact(nb, oracle, lanes):
     """Data that trips the per-tile range guard: tiny, huge, subnormal-producing and coincident coordinates,
     mixed into ordinary ones so that some tiles take the ladder and others the IEEE path."""
     n = 2048
@@ -134,7 +184,7 @@ def test_strict_extreme_coordinates_bit_exact(nb, oracle):
     assert_bits_equal(v, v_ref)
 
 
-def test_strict_nonfinite_input_propagates_like_the_reference(nb, oracle):
+def test_strict_nonfinite_input_propagates_like_the_reference(nb, oracle, lanes):
     pos, vel = state3d(oracle, 300, seed=9)
     pos[17, 0] = np.inf
     pos[200, 1] = np.nan
@@ -147,7 +197,7 @@ def test_strict_nonfinite_input_propagates_like_the_reference(nb, oracle):
     assert (bits(p)[ok] == bits(p_ref)[ok]).all()
 
 
-def test_strict_nondefault_constants_bit_exact(nb, oracle):
+def test_strict_nondefault_constants_bit_exact(nb, oracle, lanes):
     pos, vel = state3d(oracle, 700, seed=21)
     for dt, g_, bias in [(0.05, 0.5, 0.01), (1.0, -0.001, 1e-3), (0.1, 1e-30, 1e-7), (0.1, 0.001, 0.0)]:
         params = nb.default_params()
@@ -210,7 +260,7 @@ def _sharded_step_on_one_gpu(nb, pos, vel, parts, params, steps):
 
 
 @pytest.mark.parametrize("parts", [[(0, 1000)], [(0, 500), (500, 500)], [(0, 1), (1, 255), (256, 257), (513, 487)]])
-def test_strict_sharded_launch_equals_unsharded(nb, oracle, parts):
+def test_strict_sharded_launch_equals_unsharded(nb, oracle, lanes, parts):
     pos, vel = state3d(oracle, 1000, seed=11)
     p, v = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(), 3)
     p_ref, v_ref = oracle.run(pos, vel, 3)
