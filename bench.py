@@ -93,10 +93,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: nenbody_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # NB_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box (ranks share devices, positions are gathered
+    # through the host): it exercises the multi-rank control flow, its numbers mean nothing.
+    backend = os.environ.get("NB_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.n
     pos, vel = nb.init_state(n, 1234)
@@ -134,7 +141,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL backend, not a measurement)",
             "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234), dt=0.1 G=0.001 bias=1e-7",
                        "mode": args.mode, "sharding": f"index range x{world}, all-gather of positions per step",
                        "tile": "library default"},

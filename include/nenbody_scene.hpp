@@ -1,0 +1,110 @@
+// nenbody_scene.hpp -- header-only C++ host mirror of the reference's update interface, over the C ABI (nenbody.h).
+//
+// The reference is compiled code (Rust) whose toolchain is absent from the build image, so besides the Rust shim
+// (integration/rust/scene.rs, uncompiled) the same host side is given in C++: `nenbody::Scene` is the type the
+// reference's empty src/scene.rs (src/scene.rs:1) was meant to hold; `nenbody::update_instance_nbody` keeps the
+// five-argument signature of src/main.rs:404-410.  Plumbing only: all arithmetic runs in libnenbody_hip.so.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nenbody.h"
+
+namespace nenbody {
+
+using Vec3 = std::array<float, 3>;                 // memory of cgmath::Point3<f32> / Vector3<f32>
+using Mat4 = std::array<std::array<float, 4>, 4>;  // memory of [[f32; 4]; 4], column-major
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+inline void check(int rc, const nb_ctx *ctx)
+{
+    if (rc != NB_OK) throw Error(rc, nb_last_error(ctx));
+}
+
+inline nb_params default_params(uint32_t mode = NB_MODE_STRICT)
+{
+    nb_params p;
+    nb_default_params(&p);  // src/main.rs:411-413
+    p.mode = mode;
+    return p;
+}
+
+class Scene {
+public:
+    std::vector<Vec3> positions;   // src/main.rs:743
+    std::vector<Vec3> velocities;  // src/main.rs:738
+    std::vector<Mat4> instances;   // instance_data, uploaded at src/main.rs:932-936
+
+    // the reference's initial distributions (src/main.rs:738-747), seeded
+    Scene(uint32_t n, const nb_params &params, uint64_t seed) : positions(n), velocities(n), instances(n)
+    {
+        check(nb_init_state(seed, n, positions[0].data(), velocities[0].data()), nullptr);
+        create(params);
+    }
+    Scene(std::vector<Vec3> pos, std::vector<Vec3> vel, const nb_params &params)
+        : positions(std::move(pos)), velocities(std::move(vel)), instances(positions.size())
+    {
+        // copy_from_slice panics on unequal lengths (src/main.rs:415-416)
+        if (positions.size() != velocities.size()) throw std::invalid_argument("positions and velocities differ in length");
+        create(params);
+    }
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+    ~Scene() { nb_destroy(ctx_); }
+
+    // one update_instance_nbody (src/main.rs:404-441); host mirrors refreshed for the consumers at src/main.rs:932-945
+    void step()
+    {
+        check(nb_step(ctx_, 1), ctx_);
+        check(nb_download(ctx_, positions[0].data(), velocities[0].data(), instances[0][0].data()), ctx_);
+    }
+    // k steps, device-resident, no download
+    void step_n(uint32_t k) { check(nb_step(ctx_, k), ctx_); }
+    void sync() { check(nb_sync(ctx_), ctx_); }
+    void refresh() { check(nb_download(ctx_, positions[0].data(), velocities[0].data(), instances[0][0].data()), ctx_); }
+    uint64_t steps_done() const { return nb_steps_done(ctx_); }
+
+private:
+    void create(const nb_params &params)
+    {
+        if (positions.empty()) throw std::invalid_argument("a Scene needs at least one body");
+        check(nb_create((uint32_t)positions.size(), 1, &params, &ctx_), nullptr);
+        int rc = nb_upload(ctx_, positions[0].data(), velocities[0].data());
+        if (rc != NB_OK) {
+            std::string msg = nb_last_error(ctx_);
+            nb_destroy(ctx_);
+            ctx_ = nullptr;
+            throw Error(rc, msg);
+        }
+    }
+    nb_ctx *ctx_ = nullptr;
+};
+
+// Drop-in for the reference's free function, src/main.rs:404-410: one upload, one step, one download per call.
+inline void update_instance_nbody(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &old_positions,
+                                  std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities)
+{
+    if (old_positions.size() != positions.size() || old_velocities.size() != velocities.size())
+        throw std::invalid_argument("source slice length does not match destination slice length");  // copy_from_slice
+    old_positions = positions;    // src/main.rs:415
+    old_velocities = velocities;  // src/main.rs:416
+    const size_t count = std::min({instances.size(), positions.size(), velocities.size()});  // zip, src/main.rs:420-423
+    if (count == 0) return;
+    std::vector<Vec3> vel_full = velocities;
+    vel_full.resize(positions.size(), Vec3{0.f, 0.f, 0.f});  // bodies past the zip are computed and dropped
+    Scene scene(old_positions, vel_full, default_params());
+    scene.step();
+    std::copy_n(scene.positions.begin(), count, positions.begin());
+    std::copy_n(scene.velocities.begin(), count, velocities.begin());
+    std::copy_n(scene.instances.begin(), count, instances.begin());
+}
+
+}  // namespace nenbody

@@ -125,9 +125,16 @@ class ShardedScene:
         if self.world > 1:
             lo = self.rank * self.slot
             mine = dst[lo:lo + self.slot]
-            if self.dist.get_backend(self.group) != "nccl":
-                mine = mine.clone()  # in-place (aliased) all-gather is an NCCL/RCCL convention
-            self.dist.all_gather_into_tensor(dst, mine, group=self.group)
+            if self.dist.get_backend(self.group) == "nccl":
+                # RCCL, in place: the send buffer is this rank's slot of the receive buffer
+                self.dist.all_gather_into_tensor(dst, mine, group=self.group)
+            elif dst.device.type == "cpu":
+                self.dist.all_gather_into_tensor(dst, mine.clone(), group=self.group)
+            else:
+                # rehearsal path (gloo with device buffers, e.g. several ranks sharing one GPU): stage through the host
+                full = self.torch.empty(dst.shape, dtype=dst.dtype)
+                self.dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
+                dst.copy_(full)
         self.cur ^= 1
         self.steps_done += 1
 
@@ -151,9 +158,11 @@ class ShardedScene:
         """All n velocities, gathered on demand (not part of the per-step exchange)."""
         if self.world == 1:
             return self.local_velocities()
-        slot_v = self.torch.zeros((self.slot, 4), dtype=self.torch.float32, device=self.device)
-        slot_v[: self.count] = self.vel[: self.count]
-        full = self.torch.zeros((self.slot * self.world, 4), dtype=self.torch.float32, device=self.device)
+        on_host = self.dist.get_backend(self.group) != "nccl"
+        dev = "cpu" if on_host else self.device
+        slot_v = self.torch.zeros((self.slot, 4), dtype=self.torch.float32, device=dev)
+        slot_v[: self.count] = self.vel[: self.count].to(dev)
+        full = self.torch.zeros((self.slot * self.world, 4), dtype=self.torch.float32, device=dev)
         self.dist.all_gather_into_tensor(full, slot_v, group=self.group)
         return full[: self.n, :3].cpu().numpy().copy()
 

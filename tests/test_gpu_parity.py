@@ -425,3 +425,53 @@ def test_instances_edge_cases(nb, oracle):
     ref = oracle.instances(pos, vel)
     assert np.allclose(got, ref, rtol=0, atol=1e-6)
     assert (got[:, 3, :3] == pos).all() and (got[:, 3, 3] == 1).all() and (got[:, 2] == [0, 0, 1, 0]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# several ranks on the one GPU of this box (gloo, positions gathered through the host): the real multi-rank
+# control flow with the real HIP kernels.  RCCL itself needs one GPU per rank and is the driver's to run.
+# ---------------------------------------------------------------------------------------------------------
+def _rank_worker(rank, world, port, n, k, mode, out_dir):
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nenbody_amd
+
+        torch.cuda.set_device(0)
+        pos, vel = nenbody_amd.init_state(n, 99)
+        pos[:, 2] = np.linspace(-50, 50, n, dtype=np.float32)
+        sc = nenbody_amd.ShardedScene(pos, vel, nenbody_amd.default_params(mode=mode))
+        sc.step_n(k)
+        sc.sync()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 4096), (3, 1000)])
+def test_multirank_on_one_gpu_strict_equals_oracle(tmp_path, nb, oracle, world, n):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k = 3
+    mp.spawn(_rank_worker, args=(world, port, n, k, nb.NB_MODE_STRICT, str(tmp_path)), nprocs=world, join=True)
+    pos, vel = nb.init_state(n, 99)
+    pos[:, 2] = np.linspace(-50, 50, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert_bits_equal(got["pos"], p_ref, f"rank {r} positions")
+        assert_bits_equal(got["vel"], v_ref, f"rank {r} velocities")
