@@ -289,6 +289,168 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 
 #ifndef NBK_JP_TU
 // ------------------------------------------------------------------------------------------------
+// STRICT, producer/consumer form ("pc"): the same arithmetic and the same summation order, for shards too small
+// to fill the chip with one lane per body.
+//
+// A workgroup owns 64 bodies (lane = body) and has 10 waves.  Waves 2..9 are PRODUCERS: for a chunk of 32 j's each
+// evaluates 4 consecutive pairs per body -- everything of main.rs:428-430 except the running-sum add, i.e. the part
+// with no ordering constraint -- and writes the quotients to an LDS ring q[parity][component][body][j] (one
+// ds_write_b128 per component).  Waves 0 and 1 are CONSUMERS: wave 0 owns every body's x sum (and z sum), wave 1
+// the y sum; each walks the previous chunk's ring in j order doing `sum = sum + q` (main.rs:430), four j's per
+// ds_read_b128, so every component of every body's fold sees exactly the reference's sequence of additions.
+// One barrier per chunk; the ring is double buffered, so producers of chunk c overlap the consumers of chunk c-1.
+// Positions are staged in 256-record tiles one tile ahead (waves 0..3 load).  VALU work per pair equals the
+// one-lane-per-body kernel (the adds just run in other waves); the wave count is 10 per 64 bodies instead of 1.
+// Why two consumers: a wave alone issues one instruction per ~5 cycles, and the chain needs 1 add per j per
+// component, so a single consumer for both components would cap the step at N x 15 cycles.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPcConsumers = 2;
+constexpr int kPcProducers = 8;
+constexpr int kPcWaves = kPcConsumers + kPcProducers;
+constexpr int kPcThreads = kPcWaves * 64;
+constexpr int kPcPer = 4;                                // consecutive j's per producer per chunk
+constexpr int kPcChunk = kPcProducers * kPcPer;          // 32 j's per chunk
+constexpr int kPcStride = kPcChunk + 4;                  // floats per body row: 144 B keeps rows 16-B aligned and spreads banks
+constexpr int kPcTile = 256;                             // position records per staging tile
+constexpr int kPcChunksPerTile = kPcTile / kPcChunk;     // 8
+
+struct PcRing {
+    float q[3][64][kPcStride];  // [component][body][j within chunk]
+};
+
+template <bool IEEE, bool PLANAR>
+__device__ __forceinline__ void pc_produce(const float4 *chunk, int j0, int lane, float xi, float yi, float zi, float G,
+                                           PcRing &ring)
+{
+    float qx[kPcPer], qy[kPcPer], qz[kPcPer];
+#pragma unroll
+    for (int t = 0; t < kPcPer; ++t) pair_strict<IEEE, PLANAR>(chunk[j0 + t], xi, yi, zi, G, qx[t], qy[t], qz[t]);
+    // records past the end of the set are zero-padded by the loader; whatever they produce is never added
+    *reinterpret_cast<float4 *>(&ring.q[0][lane][j0]) = make_float4(qx[0], qx[1], qx[2], qx[3]);
+    *reinterpret_cast<float4 *>(&ring.q[1][lane][j0]) = make_float4(qy[0], qy[1], qy[2], qy[3]);
+    if (!PLANAR) *reinterpret_cast<float4 *>(&ring.q[2][lane][j0]) = make_float4(qz[0], qz[1], qz[2], qz[3]);
+}
+
+// sum = sum + q[j] for j = 0 .. nvalid-1 in order: main.rs:430 for one component of one body per lane
+__device__ __forceinline__ void pc_consume(const float (*row)[kPcStride], int lane, int nvalid, float &sum)
+{
+    float4 r[kPcChunk / 4];
+#pragma unroll
+    for (int g = 0; g < kPcChunk / 4; ++g) r[g] = *reinterpret_cast<const float4 *>(&row[lane][4 * g]);
+    if (nvalid == kPcChunk) {
+#pragma unroll
+        for (int g = 0; g < kPcChunk / 4; ++g) {
+            sum = sum + r[g].x;
+            sum = sum + r[g].y;
+            sum = sum + r[g].z;
+            sum = sum + r[g].w;
+        }
+    } else {  // last chunk of the set
+#pragma unroll
+        for (int g = 0; g < kPcChunk / 4; ++g) {
+            if (4 * g + 0 < nvalid) sum = sum + r[g].x;
+            if (4 * g + 1 < nvalid) sum = sum + r[g].y;
+            if (4 * g + 2 < nvalid) sum = sum + r[g].z;
+            if (4 * g + 3 < nvalid) sum = sum + r[g].w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPcThreads) void step_strict_pc_kernel(StepArgs a)
+{
+    __shared__ float4 tile[2][kPcTile];
+    __shared__ __attribute__((aligned(16))) PcRing ring[2];
+    __shared__ uint32_t tile_flags[2][4];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const uint32_t l = blockIdx.x * 64u + (uint32_t)lane;  // body index inside the shard: the same 64 bodies in every wave
+    const bool live = l < a.count;
+    const float4 pi = a.pos_in[a.first + (live ? l : a.count - 1u)];
+    const float xi = pi.x, yi = pi.y, zi = pi.z;
+
+    const uint32_t lo = a.lo_bits, span = a.hi_bits - a.lo_bits;
+    // every wave holds the same 64 bodies, so each derives the workgroup's own-body flags by itself
+    const uint32_t self = wave_or(coord_oor(xi, lo, span) | coord_oor(yi, lo, span) | coord_oor(zi, lo, span) | a.force_ieee |
+                                  nonzero_bits(zi) | a.force_3d);
+
+    const uint32_t n = a.n_total;
+    const uint32_t nchunks = (n + (uint32_t)kPcChunk - 1u) / (uint32_t)kPcChunk;
+    const uint32_t ntiles = (n + (uint32_t)kPcTile - 1u) / (uint32_t)kPcTile;
+    const bool loader = tid < kPcTile;  // waves 0..3
+    auto fetch = [&](uint32_t t) -> float4 {
+        const uint32_t j = t * (uint32_t)kPcTile + (uint32_t)tid;
+        return (loader && j < n) ? a.pos_in[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto publish = [&](int buf, float4 rec) {
+        // Opaque use point: keeps the range/planarity checks (pure arithmetic on the prefetched record) from being
+        // hoisted out of the chunk loop, which would put the s_waitcnt for the global load right behind the load.
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));  // .w too: keeps the whole destination register range of the dwordx4 load reserved
+        if (loader) {
+            const uint32_t f = wave_or(coord_oor(rec.x, lo, span) | coord_oor(rec.y, lo, span) | coord_oor(rec.z, lo, span) |
+                                       nonzero_bits(rec.z));
+            tile[buf][tid] = make_float4(rec.x, rec.y, rec.z, a.bias);
+            if (lane == 0) tile_flags[buf][wave] = f;
+        }
+    };
+    publish(0, fetch(0u));
+    __syncthreads();
+
+    float sum0 = 0.f, sum2 = 0.f;  // main.rs:426.  wave 0: sum0 = x, sum2 = z;  wave 1: sum0 = y
+    uint32_t prev_flags = 0u;      // flags of the chunk the consumers fold next (the producers' previous chunk)
+    for (uint32_t t = 0; t <= ntiles; ++t) {  // one extra pass drains the last chunk
+        const int tb = (int)(t & 1u);
+        const bool have_tile = t < ntiles;
+        const bool stage = t + 1u < ntiles;
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (stage) rec = fetch(t + 1u);  // global loads stay in flight across the chunks of this tile
+        uint32_t cur_flags = self;
+        if (have_tile) cur_flags |= tile_flags[tb][0] | tile_flags[tb][1] | tile_flags[tb][2] | tile_flags[tb][3];
+        const uint32_t kmax = have_tile ? (uint32_t)kPcChunksPerTile : 1u;
+        for (uint32_t k = 0; k < kmax; ++k) {
+            const uint32_t c = t * (uint32_t)kPcChunksPerTile + k;  // global chunk index
+            if (c > nchunks) break;                                 // uniform
+            const int qb = (int)(c & 1u);
+            if (wave < kPcConsumers) {
+                if (c >= 1u) {  // fold chunk c-1, written during the previous iteration
+                    const uint32_t left = n - (c - 1u) * (uint32_t)kPcChunk;
+                    const int nvalid = left < (uint32_t)kPcChunk ? (int)left : kPcChunk;
+                    pc_consume(ring[qb ^ 1].q[wave], lane, nvalid, sum0);
+                    if (wave == 0 && (prev_flags & (kFlagNonPlanar | kFlagIeee)) != 0u)
+                        pc_consume(ring[qb ^ 1].q[2], lane, nvalid, sum2);
+                }
+            } else if (c < nchunks) {
+                const int j0 = (wave - kPcConsumers) * kPcPer;
+                const float4 *chunk = tile[tb] + k * (uint32_t)kPcChunk;
+                if (cur_flags == 0u)
+                    pc_produce<false, true>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
+                else if ((cur_flags & kFlagIeee) == 0u)
+                    pc_produce<false, false>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
+                else
+                    pc_produce<true, false>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
+            }
+            prev_flags = cur_flags;
+            // Tile t+1 goes to the buffer tile t-1 used: its producers finished at least one barrier ago.
+            if (stage && k == kmax - 1u) publish(tb ^ 1, rec);
+            __syncthreads();
+        }
+    }
+
+    // the y sums live in wave 1: hand them to wave 0 through the ring (all folds are done)
+    if (wave == 1) ring[0].q[1][lane][0] = sum0;
+    __syncthreads();
+    if (wave == 0 && live) {
+        const float sy = ring[0].q[1][lane][0];
+        float4 p = pi;
+        float4 v = a.vel[l];
+        integrate(p, v, sum0, sy, sum2, a.dt);
+        a.vel[l] = v;
+        a.pos_out[a.first + l] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FAST arithmetic
 // ------------------------------------------------------------------------------------------------
 template <int IB, int U, bool PLANAR>
@@ -508,6 +670,12 @@ hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, u
     return hipErrorInvalidValue;
 }
 #else
+hipError_t launch_strict_pc(const StepArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(step_strict_pc_kernel, dim3(ceil_div(a.count, 64)), dim3(kPcThreads), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s)
 {
     if (lanes > 1) return launch_strict_jp(a, tile, unroll, lanes, s);

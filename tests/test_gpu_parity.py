@@ -40,11 +40,16 @@ def state3d(oracle, n, seed):
 # ---------------------------------------------------------------------------------------------------------
 # STRICT: bit-exact
 # ---------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 4, 8, 16], ids=lambda s: f"lanes{s}")
+@pytest.fixture(params=[1, 2, 4, 8, 16, "pc"], ids=lambda s: f"lanes{s}")
 def lanes(request, monkeypatch):
-    """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel with the same summation order).
-    By default the library picks it from the shard size; the tests pin every value."""
-    monkeypatch.setenv("NB_STRICT_LANES", str(request.param))
+    """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel) or "pc" = producer/consumer form.
+    All of them keep the reference's summation order.  By default the library picks one from the shard size;
+    the tests pin every value."""
+    if request.param == "pc":
+        monkeypatch.setenv("NB_STRICT_PC", "1")
+    else:
+        monkeypatch.setenv("NB_STRICT_PC", "0")
+        monkeypatch.setenv("NB_STRICT_LANES", str(request.param))
     return request.param
 
 
@@ -109,9 +114,12 @@ def test_strict_every_tile_size_bit_exact(nb, oracle, tile):
     assert_bits_equal(v, v_ref)
 
 
-@pytest.mark.parametrize("force_lanes", [None, 1, 4])
+@pytest.mark.parametrize("force_lanes", [None, 1, 4, "pc"])
 def test_strict_golden_n16_and_n1024(nb, monkeypatch, force_lanes):
-    if force_lanes is not None:
+    if force_lanes == "pc":
+        monkeypatch.setenv("NB_STRICT_PC", "1")
+    elif force_lanes is not None:
+        monkeypatch.setenv("NB_STRICT_PC", "0")
         monkeypatch.setenv("NB_STRICT_LANES", str(force_lanes))
     g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden.npz"))
     seed = int(g["seed"][0])

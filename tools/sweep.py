@@ -117,6 +117,37 @@ def main():
         return shard_sweep()
     if what == "lanes":
         return lanes_sweep()
+    if what == "pc":
+        import torch
+
+        from nenbody_amd.dist import HipBackend
+
+        be = HipBackend()
+        dev = torch.device("cuda", 0)
+        n_total = 131072
+        pos, vel = nb.init_state(n_total, 1234)
+        cur = torch.zeros((n_total, 4)); cur[:, :3] = torch.from_numpy(pos); cur = cur.to(dev)
+        nxt = torch.zeros_like(cur)
+        for f3d in (0, 1):
+            for world in (1, 2, 4, 8):
+                count = n_total // world
+                for pc in (0, 1):
+                    env = {"NB_STRICT_PC": pc, "NB_FORCE_3D": f3d}
+                    for k, v in env.items():
+                        os.environ[k] = str(v)
+                    params = nb.default_params(mode=nb.NB_MODE_STRICT)
+                    v4 = torch.zeros((count, 4), device=dev)
+                    for _ in range(2):
+                        be.step(params, n_total, 0, count, cur, nxt, v4, None)
+                    torch.cuda.synchronize()
+                    reps = 4
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        be.step(params, n_total, 0, count, cur, nxt, v4, None)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / reps
+                    print(f"3d={f3d} world={world} count={count:7d} pc={pc} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
+        return
     if what == "strict2":
         for env in ({}, {"NB_FORCE_3D": 1}, {"NB_STRICT_UNROLL": 8}, {"NB_FORCE_3D": 1, "NB_STRICT_UNROLL": 8},
                     {"NB_TILE": 1024}, {"NB_TILE": 1024, "NB_STRICT_UNROLL": 8}):
