@@ -25,6 +25,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BYTES_PER_BODY_STEP = 64          # algorithmic HBM bytes: 16-B position + 16-B velocity record, read and written once
+
+
+def measured_traffic(kernel, n, count):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes, or None if this run's shape differs."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if t["n"] == n and t["count"] == count:
+            return t["kernels"][kernel]["bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 FLOP_PER_INTERACTION = 18         # src/main.rs:428-430 as written: 3 sub, 3 mul + 2 add, 1 add, 3 mul, 3 div, 3 add
 
 
@@ -124,7 +136,9 @@ def main():
             "ms_per_step": 1e3 / steps_per_s,
             "kernel_ms": r["kernel_ms"],
             "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "traffic": measured_traffic(r["kernel"], r["n"], r["count"]), "traffic_unit": "bytes/launch (HBM, PMC)",
+                         "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
                          "kernel": r["kernel"],
                          "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"]},
         }
