@@ -43,7 +43,7 @@ struct Plan {
     uint32_t force_3d;                      // 2 = never take the planar shortcut (NB_FORCE_3D=1: tests, measurements)
     uint32_t unroll;                        // STRICT: pairs in flight per lane (2, 4 or 8)
     uint32_t lanes;                         // STRICT: lanes per body (1 = plain; 2..16 = j-parallel, same summation order)
-    uint32_t pc;                            // STRICT: 1 = producer/consumer form (64 bodies x 9 waves per workgroup)
+    uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
 };
 
 int floor_log2f(float x)
@@ -135,10 +135,13 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (pl.lanes == 16) pl.unroll = 2;
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 512) pl.tile = 1024;  // built j-parallel shapes: 256, 1024
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 1024 && pl.unroll == 2 && pl.lanes < 8) pl.unroll = 4;
-    // Producer/consumer form: ahead of the j-parallel form only while a shard gives at most one 64-body workgroup
-    // per CU (measured at 16 384 bodies: 2.20 vs 2.30 ms planar, 2.68 vs 3.22 ms 3-D; profiles/r01_jp/).
-    pl.pc = (count <= 16384u) ? 1u : 0u;
+    // Producer/consumer form (14 producers + 2 consumers per 64 bodies) for every shard below 65 536 bodies: measured
+    // at N = 131 072 (profiles/r01_jp/pc_sweep.log): 16 384 bodies 1.35 ms (j-parallel S=8: 2.30), 32 768: 2.66 (S=4: 3.55),
+    // 65 536: 5.31 -- there one lane per body wins again (4.77).
+    pl.pc = (count < 65536u) ? 14u : 0u;
     env_u32("NB_STRICT_PC", &pl.pc);
+    if (pl.pc == 1) pl.pc = 8;
+    if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
     *out = pl;
     return NB_OK;
 }
@@ -167,7 +170,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.force_ieee = pl.force_ieee;
     a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
-    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.pc ? nbk::launch_strict_pc(a, stream)
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
     if (e != hipSuccess) {

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 // STRICT, producer/consumer form ("pc"): the same arithmetic and the same summation order, for shards too small
 // to fill the chip with one lane per body.
 //
-// A workgroup owns 64 bodies (lane = body) and has 10 waves.  Waves 2..9 are PRODUCERS: for a chunk of 32 j's each
-// evaluates 4 consecutive pairs per body -- everything of main.rs:428-430 except the running-sum add, i.e. the part
+// A workgroup owns 64 bodies (lane = body) and has 2 + NP waves (NP = 8 or 14).  Waves 2.. are PRODUCERS: for a chunk of
+// 4*NP j's each evaluates 4 consecutive pairs per body -- everything of main.rs:428-430 except the running-sum add, i.e. the part
 // with no ordering constraint -- and writes the quotients to an LDS ring q[parity][component][body][j] (one
 // ds_write_b128 per component).  Waves 0 and 1 are CONSUMERS: wave 0 owns every body's x sum (and z sum), wave 1
 // the y sum; each walks the previous chunk's ring in j order doing `sum = sum + q` (main.rs:430), four j's per
@@ -305,22 +305,27 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
 // component, so a single consumer for both components would cap the step at N x 15 cycles.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPcConsumers = 2;
-constexpr int kPcProducers = 8;
-constexpr int kPcWaves = kPcConsumers + kPcProducers;
-constexpr int kPcThreads = kPcWaves * 64;
-constexpr int kPcPer = 4;                                // consecutive j's per producer per chunk
-constexpr int kPcChunk = kPcProducers * kPcPer;          // 32 j's per chunk
-constexpr int kPcStride = kPcChunk + 4;                  // floats per body row: 144 B keeps rows 16-B aligned and spreads banks
-constexpr int kPcTile = 256;                             // position records per staging tile
-constexpr int kPcChunksPerTile = kPcTile / kPcChunk;     // 8
+constexpr int kPcPer = 4;  // consecutive j's per producer per chunk
 
-struct PcRing {
-    float q[3][64][kPcStride];  // [component][body][j within chunk]
+// Shape of one producer/consumer workgroup, by producer count NP (8 or 14)
+template <int NP>
+struct PcShape {
+    static constexpr int kWaves = kPcConsumers + NP;
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kChunk = NP * kPcPer;        // j's per chunk: 32 / 56
+    static constexpr int kStride = kChunk + 4;        // floats per body row: rows stay 16-B aligned, banks spread
+    static constexpr int kChunksPerTile = 8;
+    static constexpr int kTile = kChunk * kChunksPerTile;  // position records per staging tile: 256 / 448
+    static constexpr int kLoaderWaves = kTile / 64;
+    static_assert(kTile % 64 == 0 && kTile <= kThreads, "tile is loaded one record per thread");
+    struct Ring {
+        float q[3][64][kStride];  // [component][body][j within chunk]
+    };
 };
 
-template <bool IEEE, bool PLANAR>
+template <int NP, bool IEEE, bool PLANAR>
 __device__ __forceinline__ void pc_produce(const float4 *chunk, int j0, int lane, float xi, float yi, float zi, float G,
-                                           PcRing &ring)
+                                           typename PcShape<NP>::Ring &ring)
 {
     float qx[kPcPer], qy[kPcPer], qz[kPcPer];
 #pragma unroll
@@ -331,39 +336,78 @@ __device__ __forceinline__ void pc_produce(const float4 *chunk, int j0, int lane
     if (!PLANAR) *reinterpret_cast<float4 *>(&ring.q[2][lane][j0]) = make_float4(qz[0], qz[1], qz[2], qz[3]);
 }
 
-// sum = sum + q[j] for j = 0 .. nvalid-1 in order: main.rs:430 for one component of one body per lane
-__device__ __forceinline__ void pc_consume(const float (*row)[kPcStride], int lane, int nvalid, float &sum)
+// sum = sum + q[j] for j = 0 .. nvalid-1 in order: main.rs:430 for one component of one body per lane.
+// Read in two halves (at most 7 float4 = 28 registers in flight) so the consumer role does not set the kernel's
+// register count.
+template <int NP>
+__device__ __forceinline__ void pc_consume(const float (*row)[PcShape<NP>::kStride], int lane, int nvalid, float &sum)
 {
-    float4 r[kPcChunk / 4];
+    constexpr int kChunk = PcShape<NP>::kChunk;
+    constexpr int kHalf = kChunk / 8;  // float4 per half: 4 (NP = 8) or 7 (NP = 14)
+    const float *base = &row[lane][0];
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        float4 r[kHalf];
 #pragma unroll
-    for (int g = 0; g < kPcChunk / 4; ++g) r[g] = *reinterpret_cast<const float4 *>(&row[lane][4 * g]);
-    if (nvalid == kPcChunk) {
+        for (int g = 0; g < kHalf; ++g) r[g] = *reinterpret_cast<const float4 *>(base + 4 * (h * kHalf + g));
+        const int j0 = 4 * h * kHalf;
+        if (nvalid == kChunk) {
 #pragma unroll
-        for (int g = 0; g < kPcChunk / 4; ++g) {
-            sum = sum + r[g].x;
-            sum = sum + r[g].y;
-            sum = sum + r[g].z;
-            sum = sum + r[g].w;
-        }
-    } else {  // last chunk of the set
+            for (int g = 0; g < kHalf; ++g) {
+                sum = sum + r[g].x;
+                sum = sum + r[g].y;
+                sum = sum + r[g].z;
+                sum = sum + r[g].w;
+            }
+        } else {  // last chunk of the set
 #pragma unroll
-        for (int g = 0; g < kPcChunk / 4; ++g) {
-            if (4 * g + 0 < nvalid) sum = sum + r[g].x;
-            if (4 * g + 1 < nvalid) sum = sum + r[g].y;
-            if (4 * g + 2 < nvalid) sum = sum + r[g].z;
-            if (4 * g + 3 < nvalid) sum = sum + r[g].w;
+            for (int g = 0; g < kHalf; ++g) {
+                if (j0 + 4 * g + 0 < nvalid) sum = sum + r[g].x;
+                if (j0 + 4 * g + 1 < nvalid) sum = sum + r[g].y;
+                if (j0 + 4 * g + 2 < nvalid) sum = sum + r[g].z;
+                if (j0 + 4 * g + 3 < nvalid) sum = sum + r[g].w;
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(kPcThreads) void step_strict_pc_kernel(StepArgs a)
+// The nk chunk steps of one tile: step k = work(k, k & 1), then a barrier; `publish` (tile staging) runs before the last
+// barrier.  Two steps per loop trip so the ring parity is a literal, and no per-step condition other than the trip
+// count: the chunk loop is otherwise bound by the CU's single scalar unit (~35 SALU ops and several branches per wave
+// per chunk doubled the step time when roles, paths and tails were decided inside it).
+template <class Work, class Publish>
+__device__ __forceinline__ void pc_steps(int nk, Work work, Publish publish)
 {
-    __shared__ float4 tile[2][kPcTile];
-    __shared__ __attribute__((aligned(16))) PcRing ring[2];
-    __shared__ uint32_t tile_flags[2][4];
+    int k = 0;
+    for (; k + 2 < nk; k += 2) {  // k stays even; leaves one or two steps
+        work(k, 0);
+        __syncthreads();
+        work(k + 1, 1);
+        __syncthreads();
+    }
+    if (nk - k == 2) {
+        work(k, 0);
+        __syncthreads();
+        ++k;
+        work(k, 1);
+    } else {
+        work(k, 0);
+    }
+    publish();
+    __syncthreads();
+}
+
+template <int NP>
+__global__ __launch_bounds__(PcShape<NP>::kThreads) void step_strict_pc_kernel(StepArgs a)
+{
+    using Sh = PcShape<NP>;
+    constexpr int kChunk = Sh::kChunk, kTile = Sh::kTile, kChunksPerTile = Sh::kChunksPerTile;
+    __shared__ float4 tile[2][kTile];
+    __shared__ __attribute__((aligned(16))) typename Sh::Ring ring[2];
+    __shared__ uint32_t tile_flags[2][Sh::kLoaderWaves];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: role branches become scalar
     const int lane = tid & 63;
     const uint32_t l = blockIdx.x * 64u + (uint32_t)lane;  // body index inside the shard: the same 64 bodies in every wave
     const bool live = l < a.count;
@@ -376,17 +420,18 @@ __global__ __launch_bounds__(kPcThreads) void step_strict_pc_kernel(StepArgs a)
                                   nonzero_bits(zi) | a.force_3d);
 
     const uint32_t n = a.n_total;
-    const uint32_t nchunks = (n + (uint32_t)kPcChunk - 1u) / (uint32_t)kPcChunk;
-    const uint32_t ntiles = (n + (uint32_t)kPcTile - 1u) / (uint32_t)kPcTile;
-    const bool loader = tid < kPcTile;  // waves 0..3
+    const uint32_t ntiles = (n + (uint32_t)kTile - 1u) / (uint32_t)kTile;
+    const uint32_t nfull = n / (uint32_t)kTile;  // tiles whose 8 chunks are all complete
+    const bool loader = wave < Sh::kLoaderWaves;
     auto fetch = [&](uint32_t t) -> float4 {
-        const uint32_t j = t * (uint32_t)kPcTile + (uint32_t)tid;
+        const uint32_t j = t * (uint32_t)kTile + (uint32_t)tid;
         return (loader && j < n) ? a.pos_in[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto publish = [&](int buf, float4 rec) {
         // Opaque use point: keeps the range/planarity checks (pure arithmetic on the prefetched record) from being
-        // hoisted out of the chunk loop, which would put the s_waitcnt for the global load right behind the load.
-        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));  // .w too: keeps the whole destination register range of the dwordx4 load reserved
+        // hoisted above the chunk loop, which would put the s_waitcnt for the global load right behind the load.
+        // .w too: keeps the whole destination register range of the dwordx4 load reserved until here.
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));
         if (loader) {
             const uint32_t f = wave_or(coord_oor(rec.x, lo, span) | coord_oor(rec.y, lo, span) | coord_oor(rec.z, lo, span) |
                                        nonzero_bits(rec.z));
@@ -398,45 +443,60 @@ __global__ __launch_bounds__(kPcThreads) void step_strict_pc_kernel(StepArgs a)
     __syncthreads();
 
     float sum0 = 0.f, sum2 = 0.f;  // main.rs:426.  wave 0: sum0 = x, sum2 = z;  wave 1: sum0 = y
-    uint32_t prev_flags = 0u;      // flags of the chunk the consumers fold next (the producers' previous chunk)
-    for (uint32_t t = 0; t <= ntiles; ++t) {  // one extra pass drains the last chunk
+    uint32_t prev_flags = 0u;      // flags of the previous tile (the consumers fold its last chunk at this tile's chunk 0)
+    uint32_t last_nk = 0u;
+    for (uint32_t t = 0; t < ntiles; ++t) {
         const int tb = (int)(t & 1u);
-        const bool have_tile = t < ntiles;
         const bool stage = t + 1u < ntiles;
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (stage) rec = fetch(t + 1u);  // global loads stay in flight across the chunks of this tile
         uint32_t cur_flags = self;
-        if (have_tile) cur_flags |= tile_flags[tb][0] | tile_flags[tb][1] | tile_flags[tb][2] | tile_flags[tb][3];
-        const uint32_t kmax = have_tile ? (uint32_t)kPcChunksPerTile : 1u;
-        for (uint32_t k = 0; k < kmax; ++k) {
-            const uint32_t c = t * (uint32_t)kPcChunksPerTile + k;  // global chunk index
-            if (c > nchunks) break;                                 // uniform
-            const int qb = (int)(c & 1u);
-            if (wave < kPcConsumers) {
-                if (c >= 1u) {  // fold chunk c-1, written during the previous iteration
-                    const uint32_t left = n - (c - 1u) * (uint32_t)kPcChunk;
-                    const int nvalid = left < (uint32_t)kPcChunk ? (int)left : kPcChunk;
-                    pc_consume(ring[qb ^ 1].q[wave], lane, nvalid, sum0);
-                    if (wave == 0 && (prev_flags & (kFlagNonPlanar | kFlagIeee)) != 0u)
-                        pc_consume(ring[qb ^ 1].q[2], lane, nvalid, sum2);
-                }
-            } else if (c < nchunks) {
-                const int j0 = (wave - kPcConsumers) * kPcPer;
-                const float4 *chunk = tile[tb] + k * (uint32_t)kPcChunk;
-                if (cur_flags == 0u)
-                    pc_produce<false, true>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
-                else if ((cur_flags & kFlagIeee) == 0u)
-                    pc_produce<false, false>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
-                else
-                    pc_produce<true, false>(chunk, j0, lane, xi, yi, zi, a.G, ring[qb]);
-            }
-            prev_flags = cur_flags;
-            // Tile t+1 goes to the buffer tile t-1 used: its producers finished at least one barrier ago.
-            if (stage && k == kmax - 1u) publish(tb ^ 1, rec);
-            __syncthreads();
+#pragma unroll
+        for (int w = 0; w < Sh::kLoaderWaves; ++w) cur_flags |= tile_flags[tb][w];
+        cur_flags = __builtin_amdgcn_readfirstlane(cur_flags);
+        const uint32_t left = n - t * (uint32_t)kTile;
+        const int nk = t < nfull ? kChunksPerTile : (int)((left + (uint32_t)kChunk - 1u) / (uint32_t)kChunk);
+        last_nk = (uint32_t)nk;
+        // Tile t+1 goes to the buffer tile t-1 used: its readers finished at least one barrier ago.
+        auto stage_next = [&]() {
+            if (stage) publish(tb ^ 1, rec);
+        };
+        const bool use_z = (cur_flags & (kFlagNonPlanar | kFlagIeee)) != 0u;
+        if (wave < kPcConsumers) {
+            // at step k fold chunk k-1 (step 0: the previous tile's last chunk, ring parity 1; nothing on the first tile)
+            const bool z_prev = wave == 0 && (prev_flags & (kFlagNonPlanar | kFlagIeee)) != 0u;
+            const bool z_this = wave == 0 && use_z;
+            const bool first_tile = t == 0u;
+            pc_steps(nk, [&](int k, int par) {
+                if (k == 0 && first_tile) return;
+                pc_consume<NP>(ring[par ^ 1].q[wave], lane, kChunk, sum0);
+                if (k == 0 ? z_prev : z_this) pc_consume<NP>(ring[par ^ 1].q[2], lane, kChunk, sum2);
+            }, stage_next);
+        } else {
+            const int j0 = (wave - kPcConsumers) * kPcPer;
+            const float4 *tl = tile[tb];
+            if (cur_flags == 0u)
+                pc_steps(nk, [&](int k, int par) { pc_produce<NP, false, true>(tl + k * kChunk, j0, lane, xi, yi, zi, a.G, ring[par]); },
+                         stage_next);
+            else if ((cur_flags & kFlagIeee) == 0u)
+                pc_steps(nk, [&](int k, int par) { pc_produce<NP, false, false>(tl + k * kChunk, j0, lane, xi, yi, zi, a.G, ring[par]); },
+                         stage_next);
+            else
+                pc_steps(nk, [&](int k, int par) { pc_produce<NP, true, false>(tl + k * kChunk, j0, lane, xi, yi, zi, a.G, ring[par]); },
+                         stage_next);
         }
+        prev_flags = cur_flags;
     }
 
+    // drain: the last chunk of the step (ordered after its producers by the last barrier above)
+    if (wave < kPcConsumers) {
+        const uint32_t last_chunk_first = (ntiles - 1u) * (uint32_t)kTile + (last_nk - 1u) * (uint32_t)kChunk;
+        const int nvalid = (int)(n - last_chunk_first);  // 1 .. kChunk
+        const int rb = (int)((last_nk - 1u) & 1u);      // ring parity of chunk k within its tile is k & 1
+        pc_consume<NP>(ring[rb].q[wave], lane, nvalid, sum0);
+        if (wave == 0 && (prev_flags & (kFlagNonPlanar | kFlagIeee)) != 0u) pc_consume<NP>(ring[rb].q[2], lane, nvalid, sum2);
+    }
+    __syncthreads();
     // the y sums live in wave 1: hand them to wave 0 through the ring (all folds are done)
     if (wave == 1) ring[0].q[1][lane][0] = sum0;
     __syncthreads();
@@ -670,9 +730,14 @@ hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, u
     return hipErrorInvalidValue;
 }
 #else
-hipError_t launch_strict_pc(const StepArgs &a, hipStream_t s)
+hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s)
 {
-    hipLaunchKernelGGL(step_strict_pc_kernel, dim3(ceil_div(a.count, 64)), dim3(kPcThreads), 0, s, a);
+    if (producers == 8)
+        hipLaunchKernelGGL(step_strict_pc_kernel<8>, dim3(ceil_div(a.count, 64)), dim3(PcShape<8>::kThreads), 0, s, a);
+    else if (producers == 14)
+        hipLaunchKernelGGL(step_strict_pc_kernel<14>, dim3(ceil_div(a.count, 64)), dim3(PcShape<14>::kThreads), 0, s, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -40,13 +40,13 @@ def state3d(oracle, n, seed):
 # ---------------------------------------------------------------------------------------------------------
 # STRICT: bit-exact
 # ---------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 4, 8, 16, "pc"], ids=lambda s: f"lanes{s}")
+@pytest.fixture(params=[1, 2, 4, 8, 16, "pc8", "pc14"], ids=lambda s: f"lanes{s}")
 def lanes(request, monkeypatch):
     """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel) or "pc" = producer/consumer form.
     All of them keep the reference's summation order.  By default the library picks one from the shard size;
     the tests pin every value."""
-    if request.param == "pc":
-        monkeypatch.setenv("NB_STRICT_PC", "1")
+    if str(request.param).startswith("pc"):
+        monkeypatch.setenv("NB_STRICT_PC", request.param[2:])   # producers per workgroup: 8 or 14
     else:
         monkeypatch.setenv("NB_STRICT_PC", "0")
         monkeypatch.setenv("NB_STRICT_LANES", str(request.param))
@@ -114,10 +114,10 @@ def test_strict_every_tile_size_bit_exact(nb, oracle, tile):
     assert_bits_equal(v, v_ref)
 
 
-@pytest.mark.parametrize("force_lanes", [None, 1, 4, "pc"])
+@pytest.mark.parametrize("force_lanes", [None, 1, 4, "pc8", "pc14"])
 def test_strict_golden_n16_and_n1024(nb, monkeypatch, force_lanes):
-    if force_lanes == "pc":
-        monkeypatch.setenv("NB_STRICT_PC", "1")
+    if str(force_lanes).startswith("pc"):
+        monkeypatch.setenv("NB_STRICT_PC", force_lanes[2:])
     elif force_lanes is not None:
         monkeypatch.setenv("NB_STRICT_PC", "0")
         monkeypatch.setenv("NB_STRICT_LANES", str(force_lanes))

@@ -131,7 +131,7 @@ def main():
         for f3d in (0, 1):
             for world in (1, 2, 4, 8):
                 count = n_total // world
-                for pc in (0, 1):
+                for pc in (0, 8, 14):
                     env = {"NB_STRICT_PC": pc, "NB_FORCE_3D": f3d}
                     for k, v in env.items():
                         os.environ[k] = str(v)
