@@ -62,6 +62,19 @@ typedef struct nb_params {
     uint32_t mode;  /* nb_mode */
 } nb_params;
 
+/* Constants of the boids controller, update_instance_boids (src/main.rs:443-526) -- the controller the reference's
+ * event loop calls (src/main.rs:925).  Defaults are the reference's: src/main.rs:450-456. */
+typedef struct nb_boids_params {
+    float dt;               /* 0.04   main.rs:450 */
+    float rule_1_distance;  /* 1000.0 main.rs:451; compared with the SQUARED distance (main.rs:474-475) */
+    float rule_2_distance;  /* 5.0    main.rs:452 */
+    float rule_3_distance;  /* 500.0  main.rs:453; a distance between VELOCITIES (main.rs:497) */
+    float rule_1_scale;     /* 0.02   main.rs:454 */
+    float rule_2_scale;     /* 0.05   main.rs:455 */
+    float rule_3_scale;     /* 0.5    main.rs:456 */
+    uint32_t tile;          /* bodies staged through LDS per tile; 0 = library default; else 256, 512 or 1024 */
+} nb_boids_params;
+
 typedef struct nb_ctx nb_ctx; /* opaque; owns the device buffers and the stream */
 
 /* -- library ------------------------------------------------------------------------------------------- */
@@ -97,6 +110,14 @@ int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz);
  * the reference's function and has no counterpart. */
 int nb_step(nb_ctx *ctx, uint32_t k);
 
+/* Fills *p with the reference constants (main.rs:450-456), tile 0. */
+void nb_boids_default_params(nb_boids_params *p);
+
+/* k applications of update_instance_boids (src/main.rs:443-526) to the context's state, device-resident,
+ * asynchronous; bit-identical to the reference's binary32 arithmetic (the three folds run in index order, the
+ * sqrt-based radius tests are evaluated exactly).  params == NULL -> defaults.  May be mixed freely with nb_step. */
+int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *params);
+
 /* Device -> host, after waiting for queued steps.  Any of the three may be NULL.
  * inst_16n, when given, receives the model matrices of the current state (src/main.rs:437-439),
  * produced on demand by a separate kernel: they never feed back into the dynamics. */
@@ -124,6 +145,13 @@ size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t coun
  * pos_out must not alias pos_in. */
 int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
                    void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream);
+
+/* One boids step (main.rs:443-526) for bodies [first, first+count) of a set of n_total:
+ *   pos_in, vel_in    n_total records each: the snapshots old_positions / old_velocities (main.rs:459-460), read only
+ *   pos_out, vel_out  n_total records each; only [first, first+count) is written (a multi-GPU caller all-gathers BOTH)
+ * The outputs must not alias the inputs. */
+int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                         const void *vel_in, void *pos_out, void *vel_out, void *stream);
 
 /* Model matrices (main.rs:437-439) for `count` bodies: pos, vel -> inst (16 floats per body). */
 int nb_launch_instances(uint32_t count, const void *pos, const void *vel, void *inst_16n, void *stream);

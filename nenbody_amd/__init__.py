@@ -4,9 +4,11 @@ One path only: ``update_instance_nbody`` (reference src/main.rs:404-441), behind
 (include/nenbody.h, libnenbody_hip.so).  This package is the thin host side: a ctypes binding, a
 ``Scene`` that mirrors the reference's update interface, and a sharded scene for one process per GPU.
 """
-from ._lib import (NB_MODE_FAST, NB_MODE_STRICT, NbError, NbParams, default_params, load)  # noqa: F401
-from .scene import Scene, init_state, update_instance_nbody  # noqa: F401
+from ._lib import (NB_MODE_FAST, NB_MODE_STRICT, NbBoidsParams, NbError, NbParams, default_boids_params,  # noqa: F401
+                   default_params, load)
+from .scene import Scene, init_state, update_instance_boids, update_instance_nbody  # noqa: F401
 from .dist import ShardedScene, partition  # noqa: F401
 
-__all__ = ["Scene", "ShardedScene", "partition", "init_state", "update_instance_nbody", "default_params", "load",
-           "NbParams", "NbError", "NB_MODE_STRICT", "NB_MODE_FAST"]
+__all__ = ["Scene", "ShardedScene", "partition", "init_state", "update_instance_nbody", "update_instance_boids",
+           "default_params", "default_boids_params", "load", "NbParams", "NbBoidsParams", "NbError", "NB_MODE_STRICT",
+           "NB_MODE_FAST"]

@@ -46,6 +46,13 @@ class NbParams(ctypes.Structure):
         return f"NbParams(dt={self.dt}, G={self.G}, bias={self.bias}, tile={self.tile}, mode={self.mode})"
 
 
+class NbBoidsParams(ctypes.Structure):
+    """struct nb_boids_params (include/nenbody.h); defaults are the reference's src/main.rs:450-456."""
+
+    _fields_ = [("dt", c_float), ("rule_1_distance", c_float), ("rule_2_distance", c_float), ("rule_3_distance", c_float),
+                ("rule_1_scale", c_float), ("rule_2_scale", c_float), ("rule_3_scale", c_float), ("tile", c_uint32)]
+
+
 class NbError(RuntimeError):
     """A non-zero nb_status from the library."""
 
@@ -66,6 +73,10 @@ PROTOTYPES = {
     "nb_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nb_step": (c_int, [c_void_p, c_uint32]),
     "nb_download": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_boids_default_params": (None, [POINTER(NbBoidsParams)]),
+    "nb_step_boids": (c_int, [c_void_p, c_uint32, POINTER(NbBoidsParams)]),
+    "nb_launch_boids_step": (
+        c_int, [POINTER(NbBoidsParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),
@@ -81,6 +92,30 @@ PROTOTYPES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """Make a torch process hold ONE HIP runtime.
+
+    libnenbody_hip.so needs `libamdhip64.so.7` (by SONAME); torch's wheels bundle their own copy with the same SONAME
+    but load it by FILE name (`libamdhip64.so`, RPATH $ORIGIN), so without help the process ends up with two runtimes:
+    streams and events of one mean nothing to the other, and whichever initialises second may find no device.
+    Loading torch's copy first (no `import torch` needed) makes both the library and torch resolve to it.  A process
+    without torch (the C++/Rust hosts) simply uses the system runtime.  NENBODY_SYSTEM_HIP=1 skips this.
+    """
+    if os.environ.get("NENBODY_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover - best effort; the loader falls back to the system runtime
+        pass
+
+
 def load() -> ctypes.CDLL:
     """Load libnenbody_hip.so (built by nenbody_amd/csrc/Makefile or __graft_entry__.build())."""
     global _lib
@@ -91,6 +126,7 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `make -C nenbody_amd/csrc` (hipcc, gfx950). "
             "nenbody_amd has no CPU fallback."
         )
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -107,6 +143,13 @@ def default_params(mode: int = NB_MODE_STRICT, tile: int = 0) -> NbParams:
     p = NbParams()
     load().nb_default_params(ctypes.byref(p))
     p.mode = mode
+    p.tile = tile
+    return p
+
+
+def default_boids_params(tile: int = 0) -> NbBoidsParams:
+    p = NbBoidsParams()
+    load().nb_boids_default_params(ctypes.byref(p))
     p.tile = tile
     return p
 

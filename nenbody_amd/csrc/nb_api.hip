@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -196,6 +197,64 @@ int check_device(std::string *err)
     return NB_OK;
 }
 
+// Largest binary32 x >= 0 with sqrtf(x) < r (correctly rounded sqrt, as the reference's f32::sqrt), or -1 if there is
+// none: then `sqrtf(d2) < r` <=> `d2 <= T` for every d2 (NaN fails both; sqrt and rounding are monotonic).
+float sqrt_threshold(float r)
+{
+    if (!(r > 0.0f)) return -1.0f;  // r <= 0 or NaN: sqrt(d2) >= 0 is never below it
+    uint32_t lo = 0u, hi = 0x7f7fffffu;  // bit patterns of +0 .. FLT_MAX: monotonic in value
+    auto below = [&](uint32_t b) {
+        float x;
+        std::memcpy(&x, &b, 4);
+        return std::sqrt(x) < r;
+    };
+    if (!below(lo)) return -1.0f;
+    if (below(hi)) {
+        float x;
+        std::memcpy(&x, &hi, 4);
+        return x;
+    }
+    while (hi - lo > 1u) {  // invariant: below(lo) && !below(hi)
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (below(mid))
+            lo = mid;
+        else
+            hi = mid;
+    }
+    float x;
+    std::memcpy(&x, &lo, 4);
+    return x;
+}
+
+int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,
+                    uint32_t *tile, std::string *err)
+{
+    if (n_total == 0 || count == 0 || (uint64_t)first + count > n_total) {
+        *err = "nb: boids: need count > 0 and [first, first+count) inside n_total";
+        return NB_ERR_INVALID;
+    }
+    uint32_t t = p.tile ? p.tile : 256u;
+    if (p.tile == 0) env_u32("NB_BOIDS_TILE", &t);
+    if (!valid_tile(t)) {
+        *err = "nb: boids params.tile must be 0, 256, 512 or 1024";
+        return NB_ERR_INVALID;
+    }
+    nbk::BoidsArgs a{};
+    a.n_total = n_total;
+    a.first = first;
+    a.count = count;
+    a.dt = p.dt;
+    a.r1 = p.rule_1_distance;
+    a.t2 = sqrt_threshold(p.rule_2_distance);
+    a.t3 = sqrt_threshold(p.rule_3_distance);
+    a.s1 = p.rule_1_scale;
+    a.s2 = p.rule_2_scale;
+    a.s3 = p.rule_3_scale;
+    *out = a;
+    *tile = t;
+    return NB_OK;
+}
+
 uint64_t splitmix64(uint64_t &s)
 {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -222,6 +281,7 @@ struct nb_ctx {
     hipStream_t stream = nullptr;
     float4 *pos[2] = {nullptr, nullptr};
     float4 *vel = nullptr;
+    float4 *vel_alt = nullptr;  // second velocity buffer: boids reads every old velocity, so velocities ping-pong too
     float *stage = nullptr;   // 3n floats: stride-3 staging for upload/download
     float4 *inst = nullptr;   // 4n float4, allocated on first use
     void *scratch = nullptr;
@@ -293,6 +353,7 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     if (ctx->pos[0]) (void)hipFree(ctx->pos[0]);
     if (ctx->pos[1]) (void)hipFree(ctx->pos[1]);
     if (ctx->vel) (void)hipFree(ctx->vel);
+    if (ctx->vel_alt) (void)hipFree(ctx->vel_alt);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->inst) (void)hipFree(ctx->inst);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -396,6 +457,52 @@ NB_EXPORT int nb_step(nb_ctx *ctx, uint32_t k)
     return NB_OK;
 }
 
+NB_EXPORT void nb_boids_default_params(nb_boids_params *p)
+{
+    if (!p) return;
+    p->dt = 0.04f;                // main.rs:450
+    p->rule_1_distance = 1000.0f; // main.rs:451
+    p->rule_2_distance = 5.0f;    // main.rs:452
+    p->rule_3_distance = 500.0f;  // main.rs:453
+    p->rule_1_scale = 0.02f;      // main.rs:454
+    p->rule_2_scale = 0.05f;      // main.rs:455
+    p->rule_3_scale = 0.5f;       // main.rs:456
+    p->tile = 0;
+}
+
+NB_EXPORT int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *params)
+{
+    if (!ctx) {
+        g_tls_error = "nb_step_boids: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_step_boids: no state uploaded (call nb_upload first)";
+        return NB_ERR_STATE;
+    }
+    nb_boids_params p;
+    if (params)
+        p = *params;
+    else
+        nb_boids_default_params(&p);
+    nbk::BoidsArgs a;
+    uint32_t tile = 0;
+    int rc = make_boids_args(p, ctx->n, 0, ctx->n, &a, &tile, &ctx->err);
+    if (rc != NB_OK) return rc;
+    if (!ctx->vel_alt) NB_HIP(ctx, hipMalloc((void **)&ctx->vel_alt, (size_t)ctx->n * sizeof(float4)));
+    for (uint32_t s = 0; s < k; ++s) {
+        a.pos_in = ctx->pos[ctx->cur];
+        a.pos_out = ctx->pos[ctx->cur ^ 1];
+        a.vel_in = ctx->vel;
+        a.vel_out = ctx->vel_alt;
+        NB_HIP(ctx, nbk::launch_boids(a, tile, ctx->stream));
+        ctx->cur ^= 1;
+        std::swap(ctx->vel, ctx->vel_alt);
+        ctx->steps++;
+    }
+    return NB_OK;
+}
+
 NB_EXPORT int nb_sync(nb_ctx *ctx)
 {
     if (!ctx) {
@@ -482,6 +589,36 @@ NB_EXPORT int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t
     rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
     return launch_step_planned(p, pl, n_total, first, count, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count,
+                                   const void *pos_in, const void *vel_in, void *pos_out, void *vel_out, void *stream)
+{
+    nb_boids_params p;
+    if (params)
+        p = *params;
+    else
+        nb_boids_default_params(&p);
+    if (!pos_in || !vel_in || !pos_out || !vel_out || pos_in == pos_out || vel_in == vel_out) {
+        g_tls_error = "nb_launch_boids_step: buffers must be non-null and the outputs must not alias the inputs";
+        return NB_ERR_INVALID;
+    }
+    nbk::BoidsArgs a;
+    uint32_t tile = 0;
+    int rc = make_boids_args(p, n_total, first, count, &a, &tile, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    a.pos_in = (const float4 *)pos_in;
+    a.vel_in = (const float4 *)vel_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel_out = (float4 *)vel_out;
+    hipError_t e = nbk::launch_boids(a, tile, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb: boids kernel launch failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
 }
 
 #define NB_LAUNCH_TLS(call)                                                                  \

@@ -19,6 +19,20 @@ struct StepArgs {
     uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
 };
 
+// Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
+struct BoidsArgs {
+    const float4 *pos_in;  // n_total records: old_positions (main.rs:459)
+    const float4 *vel_in;  // n_total records: old_velocities (main.rs:460)
+    float4 *pos_out;       // n_total records; [first, first+count) written
+    float4 *vel_out;       // n_total records; [first, first+count) written
+    uint32_t n_total, first, count;
+    float dt;              // main.rs:450
+    float r1;              // rule_1_distance, compared with the squared distance (main.rs:451, 474-475)
+    float t2, t3;          // squared-distance thresholds equivalent to sqrt(d2) < rule_2_distance / rule_3_distance
+    float s1, s2, s3;      // rule scales, main.rs:454-456
+};
+hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s);
+
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_JP_TU
 hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s);  // producer/consumer form: 64 bodies x (2 + producers) waves per workgroup

@@ -32,6 +32,7 @@ namespace nbk {
 
 static constexpr int kBlock = 256;   // threads per workgroup = 4 waves, one per SIMD of a CU
 static constexpr int kWaves = kBlock / 64;
+[[maybe_unused]] static inline uint32_t ceil_div_u(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
 // ------------------------------------------------------------------------------------------------
 // tile staging: global -> registers -> LDS, TJ records per tile, TJ/256 per thread
@@ -638,6 +639,144 @@ __global__ __launch_bounds__(kBlock) void integrate_partials_kernel(StepArgs a, 
     integrate(p, v, sx * a.G, sy * a.G, sz * a.G, a.dt);
     a.vel[l] = v;
     a.pos_out[a.first + l] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Boids controller: update_instance_boids, main.rs:443-526.
+//
+// Three index-ordered, predicated folds per body over the snapshots of all positions / all velocities:
+//   rule 1 (main.rs:471-480)  centre += p_i, count += 1      if |p_i - p_n|^2      < rule_1_distance && i != n
+//   rule 2 (main.rs:482-492)  repel  -= (p_i - p_n)           if sqrt(|p_i - p_n|^2) < rule_2_distance && i != n
+//   rule 3 (main.rs:494-504)  match  += v_i, vcount += 1      if sqrt(|v_i - v_n|^2) < rule_3_distance && i != n
+// One lane per body, j in index order, so every sum sees the reference's sequence of additions.  The two sqrt
+// predicates are evaluated WITHOUT a sqrt: sqrt is monotonic and correctly rounded in the reference, so
+// `sqrt(x) < r` holds exactly for x <= T(r), T(r) = the largest binary32 whose correctly rounded root is below r;
+// nb_api computes T on the host (bisection over bit patterns with the host's IEEE sqrtf).  NaN fails every test on
+// both sides.  A skipped term leaves the sum untouched (select on the result, not on the operand: -0 survives).
+// The epilogue (means, velocity blend, speed clamp, position update: main.rs:506-521) runs once per body with the
+// correctly rounded '/' and sqrt.
+// ------------------------------------------------------------------------------------------------
+template <int TJ>
+__global__ __launch_bounds__(kBlock) void boids_step_kernel(BoidsArgs a)
+{
+    __shared__ float4 tile_p[2][TJ];
+    __shared__ float4 tile_v[2][TJ];
+
+    const int tid = threadIdx.x;
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + (uint32_t)tid;
+    const bool live = l < a.count;
+    const uint32_t gn = a.first + (live ? l : a.count - 1u);  // this body's global index n
+    const float4 pn = a.pos_in[gn];
+    const float4 vn = a.vel_in[gn];
+
+    TileRegs<TJ> rp, rv;
+    const uint32_t n = a.n_total;
+    const uint32_t ntiles = (n + (uint32_t)TJ - 1u) / (uint32_t)TJ;
+    tile_fetch<TJ>(rp, a.pos_in, 0u, n, tid);
+    tile_fetch<TJ>(rv, a.vel_in, 0u, n, tid);
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < TJ / kBlock; ++k) {
+            tile_p[buf][k * kBlock + tid] = rp.r[k];
+            tile_v[buf][k * kBlock + tid] = rv.r[k];
+        }
+    };
+    publish(0);
+    __syncthreads();
+
+    float cx = 0.f, cy = 0.f, cz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
+    int cnt = 0, vcnt = 0;
+    auto pair = [&](const float4 pj, const float4 vj, uint32_t j) {
+        const bool ne = j != gn;                                       // main.rs:475 n != i
+        const float dx = pj.x - pn.x, dy = pj.y - pn.y, dz = pj.z - pn.z;  // distance2: (other - self)
+        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+        const float d2 = (xx + yy) + zz;
+        const bool p1 = (d2 < a.r1) && ne;                              // main.rs:474-475 (squared distance)
+        const float c1x = cx + pj.x, c1y = cy + pj.y, c1z = cz + pj.z;  // main.rs:476
+        cx = p1 ? c1x : cx;
+        cy = p1 ? c1y : cy;
+        cz = p1 ? c1z : cz;
+        cnt += p1 ? 1 : 0;
+        const bool p2 = (d2 <= a.t2) && ne;                             // main.rs:485-486  sqrt(d2) < rule_2_distance
+        const float r1x = rx - dx, r1y = ry - dy, r1z = rz - dz;        // main.rs:487  sum - (p_i - p_n)
+        rx = p2 ? r1x : rx;
+        ry = p2 ? r1y : ry;
+        rz = p2 ? r1z : rz;
+        const float ex = vj.x - vn.x, ey = vj.y - vn.y, ez = vj.z - vn.z;
+        const float e2 = ((ex * ex) + (ey * ey)) + (ez * ez);
+        const bool p3 = (e2 <= a.t3) && ne;                             // main.rs:497-498  sqrt(e2) < rule_3_distance
+        const float m1x = mx + vj.x, m1y = my + vj.y, m1z = mz + vj.z;  // main.rs:499
+        mx = p3 ? m1x : mx;
+        my = p3 ? m1y : my;
+        mz = p3 ? m1z : mz;
+        vcnt += p3 ? 1 : 0;
+    };
+
+    int buf = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1u) < ntiles;
+        if (more) {
+            tile_fetch<TJ>(rp, a.pos_in, (t + 1u) * (uint32_t)TJ, n, tid);
+            tile_fetch<TJ>(rv, a.vel_in, (t + 1u) * (uint32_t)TJ, n, tid);
+        }
+        const uint32_t j0 = t * (uint32_t)TJ;
+        const uint32_t left = n - j0;
+        const int nj = left < (uint32_t)TJ ? (int)left : TJ;
+        int j = 0;
+        for (; j + 4 <= nj; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pair(tile_p[buf][j + u], tile_v[buf][j + u], j0 + (uint32_t)(j + u));
+        }
+        for (; j < nj; ++j) pair(tile_p[buf][j], tile_v[buf][j], j0 + (uint32_t)j);
+        if (more) publish(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (live) {
+        if (cnt > 0) {  // main.rs:506-508
+            const float c = (float)cnt;
+            cx = cx / c;
+            cy = cy / c;
+            cz = cz / c;
+        }
+        if (vcnt > 0) {  // main.rs:510-512
+            const float c = (float)vcnt;
+            mx = mx / c;
+            my = my / c;
+            mz = mz / c;
+        }
+        // main.rs:514  vel = center*s1 + repel*s2 + match*s3, left to right, every product and sum rounded
+        const float ax = cx * a.s1, ay = cy * a.s1, az = cz * a.s1;
+        const float bx = rx * a.s2, by = ry * a.s2, bz = rz * a.s2;
+        const float gx = mx * a.s3, gy = my * a.s3, gz = mz * a.s3;
+        float vx = (ax + bx) + gx, vy = (ay + by) + gy, vz = (az + bz) + gz;
+        // main.rs:516-518  |vel| > 1 -> vel * (1 / |vel|)
+        const float q0 = vx * vx, q1 = vy * vy, q2 = vz * vz;
+        const float mag = __builtin_sqrtf((q0 + q1) + q2);  // correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt (NOT __fsqrt_rn: that is the 1-ulp v_sqrt_f32)
+        if (mag > 1.0f) {
+            const float sc = 1.0f / mag;
+            vx = vx * sc;
+            vy = vy * sc;
+            vz = vz * sc;
+        }
+        // main.rs:521  pos = vel * dt + pos
+        const float sx = vx * a.dt, sy = vy * a.dt, sz = vz * a.dt;
+        a.vel_out[a.first + l] = make_float4(vx, vy, vz, 0.f);
+        a.pos_out[a.first + l] = make_float4(sx + pn.x, sy + pn.y, sz + pn.z, 0.f);
+    }
+}
+
+hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s)
+{
+    const dim3 grid(ceil_div_u(a.count, kBlock)), block(kBlock);
+    switch (tile) {
+        case 256: hipLaunchKernelGGL(boids_step_kernel<256>, grid, block, 0, s, a); break;
+        case 512: hipLaunchKernelGGL(boids_step_kernel<512>, grid, block, 0, s, a); break;
+        case 1024: hipLaunchKernelGGL(boids_step_kernel<1024>, grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,6 +64,13 @@ class HipBackend:
         stream = torch.cuda.current_stream(pos.device).cuda_stream
         check(self.lib.nb_launch_instances(count, pos.data_ptr(), vel.data_ptr(), inst.data_ptr(), stream))
 
+    def boids_step(self, params, n_total, first, count, pos_in, vel_in, pos_out, vel_out) -> None:
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        check(self.lib.nb_launch_boids_step(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), vel_in.data_ptr(),
+                                            pos_out.data_ptr(), vel_out.data_ptr(), stream))
+
 
 class ShardedScene:
     """One rank's share of a Scene: bodies [first, first+count) plus a replica of all positions.
@@ -116,6 +123,51 @@ class ShardedScene:
         self.scratch = torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None
         self.cur = 0
         self.steps_done = 0
+        self.velfull = None      # boids only: replicas of ALL velocities (ping-pong), built on first use
+        self.velfull_valid = False
+
+    # -- the exchange: every rank contributes its slot of `buf` and receives the others -----------------------
+    def _all_gather_slots(self, buf) -> None:
+        lo = self.rank * self.slot
+        mine = buf[lo:lo + self.slot]
+        if self.dist.get_backend(self.group) == "nccl":
+            # RCCL, in place: the send buffer is this rank's slot of the receive buffer
+            self.dist.all_gather_into_tensor(buf, mine, group=self.group)
+        elif buf.device.type == "cpu":
+            self.dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
+        else:
+            # rehearsal path (gloo with device buffers, e.g. several ranks sharing one GPU): stage through the host
+            full = self.torch.empty(buf.shape, dtype=buf.dtype)
+            self.dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
+            buf.copy_(full)
+
+    # -- boids: update_instance_boids (main.rs:443-526) reads every old velocity, so velocities are replicated and
+    #    gathered like positions ----------------------------------------------------------------------------------
+    def step_boids(self, params=None) -> None:
+        torch = self.torch
+        bp = params if params is not None else _lib.default_boids_params()
+        lo = self.rank * self.slot
+        if self.velfull is None:
+            padded = self.slot * self.world
+            self.velfull = [torch.zeros((padded, 4), dtype=torch.float32, device=self.device) for _ in range(2)]
+        if not self.velfull_valid:  # (re)build the replica from the local velocities (n-body steps keep only those)
+            vf = self.velfull[self.cur]
+            if self.count:
+                vf[lo:lo + self.count] = self.vel[: self.count]
+            if self.world > 1:
+                self._all_gather_slots(vf)
+            self.velfull_valid = True
+        psrc, pdst = self.pos[self.cur], self.pos[self.cur ^ 1]
+        vsrc, vdst = self.velfull[self.cur], self.velfull[self.cur ^ 1]
+        if self.count:
+            self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, pdst, vdst)
+        if self.world > 1:
+            self._all_gather_slots(pdst)
+            self._all_gather_slots(vdst)
+        if self.count:
+            self.vel[: self.count] = vdst[lo:lo + self.count]  # keep the local velocities current for n-body steps
+        self.cur ^= 1
+        self.steps_done += 1
 
     # -- one step: local update, then the exchange ------------------------------------------------------
     def step(self) -> None:
@@ -123,18 +175,8 @@ class ShardedScene:
         if self.count:
             self.backend.step(self.params, self.n, self.first, self.count, src, dst, self.vel, self.scratch)
         if self.world > 1:
-            lo = self.rank * self.slot
-            mine = dst[lo:lo + self.slot]
-            if self.dist.get_backend(self.group) == "nccl":
-                # RCCL, in place: the send buffer is this rank's slot of the receive buffer
-                self.dist.all_gather_into_tensor(dst, mine, group=self.group)
-            elif dst.device.type == "cpu":
-                self.dist.all_gather_into_tensor(dst, mine.clone(), group=self.group)
-            else:
-                # rehearsal path (gloo with device buffers, e.g. several ranks sharing one GPU): stage through the host
-                full = self.torch.empty(dst.shape, dtype=dst.dtype)
-                self.dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
-                dst.copy_(full)
+            self._all_gather_slots(dst)
+        self.velfull_valid = False  # the velocity replica (boids only) no longer matches the local velocities
         self.cur ^= 1
         self.steps_done += 1
 

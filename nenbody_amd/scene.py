@@ -17,9 +17,10 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import NB_MODE_FAST, NB_MODE_STRICT, NbError, NbParams, check  # noqa: F401  (re-exported)
+from ._lib import NB_MODE_FAST, NB_MODE_STRICT, NbBoidsParams, NbError, NbParams, check  # noqa: F401  (re-exported)
 
-__all__ = ["Scene", "update_instance_nbody", "init_state", "NB_MODE_STRICT", "NB_MODE_FAST", "NbParams", "NbError"]
+__all__ = ["Scene", "update_instance_nbody", "update_instance_boids", "init_state", "NB_MODE_STRICT", "NB_MODE_FAST",
+           "NbParams", "NbBoidsParams", "NbError"]
 
 
 def _as_f32(a, shape_tail, name):
@@ -92,6 +93,15 @@ class Scene:
         """k updates, device-resident and asynchronous; host mirrors are NOT refreshed (see :meth:`sync`)."""
         check(self._lib.nb_step(self._ctx, int(k)), self._ctx)
 
+    def step_boids(self, params: Optional[NbBoidsParams] = None) -> None:
+        """One update_instance_boids (src/main.rs:443-526), then refresh the host mirrors."""
+        check(self._lib.nb_step_boids(self._ctx, 1, ctypes.byref(params) if params is not None else None), self._ctx)
+        self._refresh(True)
+
+    def step_boids_n(self, k: int, params: Optional[NbBoidsParams] = None) -> None:
+        """k boids updates, device-resident and asynchronous; host mirrors are NOT refreshed."""
+        check(self._lib.nb_step_boids(self._ctx, int(k), ctypes.byref(params) if params is not None else None), self._ctx)
+
     def sync(self) -> None:
         check(self._lib.nb_sync(self._ctx), self._ctx)
 
@@ -141,6 +151,44 @@ class Scene:
         return False
 
 
+def _check_update_args(instances, positions, old_positions, velocities, old_velocities):
+    for name, arr, tail in (("instances", instances, (4, 4)), ("positions", positions, (3,)),
+                            ("old_positions", old_positions, (3,)), ("velocities", velocities, (3,)),
+                            ("old_velocities", old_velocities, (3,))):
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.flags.c_contiguous and arr.flags.writeable):
+            raise TypeError(f"{name} must be a writable C-contiguous float32 numpy array")
+        if arr.ndim != len(tail) + 1 or tuple(arr.shape[1:]) != tail:
+            raise ValueError(f"{name} must have shape (n, {', '.join(map(str, tail))})")
+    if len(old_positions) != len(positions):
+        raise ValueError("source slice length does not match destination slice length (old_positions vs positions)")
+    if len(old_velocities) != len(velocities):
+        raise ValueError("source slice length does not match destination slice length (old_velocities vs velocities)")
+
+
+def update_instance_boids(instances, positions, old_positions, velocities, old_velocities,
+                          params: Optional[NbBoidsParams] = None) -> None:
+    """The reference's live controller with its own five arguments, updated in place (src/main.rs:443-449).
+
+    Same contract as :func:`update_instance_nbody` (snapshot copies first, main.rs:459-460; `zip` stops at the
+    shortest of instances / positions / velocities, main.rs:465-469).  The velocity fold (main.rs:494-504) reads
+    ``old_velocities`` for every body, so ``velocities`` must be as long as ``positions`` here.
+    """
+    _check_update_args(instances, positions, old_positions, velocities, old_velocities)
+    old_positions[...] = positions   # main.rs:459
+    old_velocities[...] = velocities  # main.rs:460
+    count = min(len(instances), len(positions), len(velocities))
+    if count == 0:
+        return
+    if len(velocities) != len(positions):
+        raise ValueError("update_instance_boids: positions and velocities must have the same length "
+                         "(the reference would index old_velocities by the enumerate() of a longer zip)")
+    with Scene(old_positions, old_velocities) as sc:
+        sc.step_boids(params)
+        positions[:count] = sc._positions[:count]
+        velocities[:count] = sc._velocities[:count]
+        instances[:count] = sc._instances[:count]
+
+
 def update_instance_nbody(instances, positions, old_positions, velocities, old_velocities,
                           params: Optional[NbParams] = None) -> None:
     """The reference's operator, same five arguments, updated in place (src/main.rs:404-410).
@@ -154,17 +202,7 @@ def update_instance_nbody(instances, positions, old_positions, velocities, old_v
     One upload, one step, one download per call: this is the drop-in form, not the fast one -- a caller
     that steps repeatedly should hold a :class:`Scene`.
     """
-    for name, arr, tail in (("instances", instances, (4, 4)), ("positions", positions, (3,)),
-                            ("old_positions", old_positions, (3,)), ("velocities", velocities, (3,)),
-                            ("old_velocities", old_velocities, (3,))):
-        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.flags.c_contiguous and arr.flags.writeable):
-            raise TypeError(f"{name} must be a writable C-contiguous float32 numpy array")
-        if arr.ndim != len(tail) + 1 or tuple(arr.shape[1:]) != tail:
-            raise ValueError(f"{name} must have shape (n, {', '.join(map(str, tail))})")
-    if len(old_positions) != len(positions):
-        raise ValueError("source slice length does not match destination slice length (old_positions vs positions)")
-    if len(old_velocities) != len(velocities):
-        raise ValueError("source slice length does not match destination slice length (old_velocities vs velocities)")
+    _check_update_args(instances, positions, old_positions, velocities, old_velocities)
     old_positions[...] = positions  # main.rs:415
     old_velocities[...] = velocities  # main.rs:416
     count = min(len(instances), len(positions), len(velocities))  # zip semantics, main.rs:420-423

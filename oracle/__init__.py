@@ -21,6 +21,13 @@ DT, G, BIAS = np.float32(0.1), np.float32(0.001), np.float32(0.0000001)
 _lib = None
 
 
+class BoidsParams(ctypes.Structure):
+    """nbo_boids_params: the constants of update_instance_boids, src/main.rs:450-456."""
+
+    _fields_ = [(k, ctypes.c_float) for k in ("dt", "rule_1_distance", "rule_2_distance", "rule_3_distance", "rule_1_scale",
+                                               "rule_2_scale", "rule_3_scale")]
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "nbody_oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
@@ -46,6 +53,12 @@ def load() -> ctypes.CDLL:
         lib.nbo_run.restype = i
         lib.nbo_run_f64.argtypes = [vp, vp, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         lib.nbo_run_f64.restype = i
+        lib.nbo_boids_default_params.argtypes = [ctypes.POINTER(BoidsParams)]
+        lib.nbo_boids_default_params.restype = None
+        lib.nbo_boids_step_range.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, ctypes.POINTER(BoidsParams)]
+        lib.nbo_boids_step_range.restype = None
+        lib.nbo_boids_run.argtypes = [vp, vp, vp, u32, u32, ctypes.POINTER(BoidsParams), i]
+        lib.nbo_boids_run.restype = i
         _lib = lib
     return _lib
 
@@ -102,3 +115,35 @@ def run_f64(pos, vel, k: int, dt=0.1, g=0.001, bias=0.0000001):
     rc = load().nbo_run_f64(p.ctypes.data, v.ctypes.data, len(p), k, dt, g, bias)
     assert rc == 0
     return p, v
+
+
+def boids_params() -> BoidsParams:
+    p = BoidsParams()
+    load().nbo_boids_default_params(ctypes.byref(p))
+    return p
+
+
+def boids_run(pos, vel, k: int, params: BoidsParams = None, threads: int = 0, want_instances: bool = False):
+    """k applications of update_instance_boids (main.rs:443-526).  Returns new (pos, vel[, instances])."""
+    p = np.ascontiguousarray(pos, np.float32).copy()
+    v = np.ascontiguousarray(vel, np.float32).copy()
+    n = len(p)
+    bp = params if params is not None else boids_params()
+    inst = np.zeros((n, 4, 4), np.float32) if want_instances else None
+    rc = load().nbo_boids_run(p.ctypes.data, v.ctypes.data, inst.ctypes.data if want_instances else None, n, k,
+                              ctypes.byref(bp), threads or ncores())
+    assert rc == 0
+    return (p, v, inst) if want_instances else (p, v)
+
+
+def boids_step_range(old_pos, old_vel, first: int, count: int, params: BoidsParams = None, want_instances: bool = False):
+    """One boids step for bodies [first, first+count) against the snapshots of all positions and velocities."""
+    op = np.ascontiguousarray(old_pos, np.float32)
+    ov = np.ascontiguousarray(old_vel, np.float32)
+    bp = params if params is not None else boids_params()
+    v = ov[first:first + count].copy()
+    p = np.empty((count, 3), np.float32)
+    inst = np.zeros((count, 4, 4), np.float32) if want_instances else None
+    load().nbo_boids_step_range(op.ctypes.data, ov.ctypes.data, p.ctypes.data, v.ctypes.data,
+                                inst.ctypes.data if want_instances else None, len(op), first, count, ctypes.byref(bp))
+    return (p, v, inst) if want_instances else (p, v)

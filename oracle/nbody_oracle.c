@@ -246,6 +246,188 @@ NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_
     return 0;
 }
 
+/* ====================================================================================
+ * Boids controller: update_instance_boids, src/main.rs:443-526 --
+ * the controller the reference's event loop actually calls (src/main.rs:925).
+ *
+ * cgmath semantics used here, besides those in the header:
+ *   MetricSpace::distance(self, other)   sqrt(distance2(self, other))          (f32::sqrt: correctly rounded)
+ *   Vector3::magnitude()                 sqrt(dot(self, self))
+ *   Vector3::normalize_to(m)             self * (m / self.magnitude())
+ * Integer literals `0` / `cnt + 1` are i32; `count as f32` is an exact conversion for counts < 2^24.
+ * ==================================================================================== */
+typedef struct nbo_boids_params {
+    float dt;               /* 0.04   main.rs:450 */
+    float rule_1_distance;  /* 1000.0 main.rs:451  (compared with the SQUARED distance, main.rs:474-475) */
+    float rule_2_distance;  /* 5.0    main.rs:452 */
+    float rule_3_distance;  /* 500.0  main.rs:453 */
+    float rule_1_scale;     /* 0.02   main.rs:454 */
+    float rule_2_scale;     /* 0.05   main.rs:455 */
+    float rule_3_scale;     /* 0.5    main.rs:456 */
+} nbo_boids_params;
+
+NBO_API void nbo_boids_default_params(nbo_boids_params *p)
+{
+    p->dt = 0.04f;
+    p->rule_1_distance = 1000.0f;
+    p->rule_2_distance = 5.0f;
+    p->rule_3_distance = 500.0f;
+    p->rule_1_scale = 0.02f;
+    p->rule_2_scale = 0.05f;
+    p->rule_3_scale = 0.5f;
+}
+
+static float dist2_f32(const float *a, const float *b) /* a.distance2(b) = (b - a).magnitude2() */
+{
+    const float ex = b[0] - a[0], ey = b[1] - a[1], ez = b[2] - a[2];
+    const float xx = ex * ex, yy = ey * ey, zz = ez * ez;
+    return (xx + yy) + zz;
+}
+
+/* One boids step for bodies [first, first+count) against the snapshots of ALL positions and velocities
+ * (old_positions / old_velocities, main.rs:459-460).  pos3_out, vel3 (in: this range's velocities, out: new) and
+ * inst16 use the local index (n - first). */
+NBO_API void nbo_boids_step_range(const float *old_pos3, const float *old_vel3, float *pos3_out, float *vel3, float *inst16,
+                                  uint32_t n_total, uint32_t first, uint32_t count, const nbo_boids_params *bp)
+{
+    for (uint32_t l = 0; l < count; ++l) {
+        const uint32_t n = first + l;
+        const float *pn = old_pos3 + 3 * (size_t)n; /* boid_n_pos == old_positions[n] until written at main.rs:521 */
+        float *v = vel3 + 3 * (size_t)l;            /* boid_n_vel == old_velocities[n] until written at main.rs:514 */
+        /* main.rs:471-480  (flock_center, count) */
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+        int32_t cnt = 0;
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const float *pi = old_pos3 + 3 * (size_t)i;
+            const float dist = dist2_f32(pn, pi);                  /* main.rs:474 distance2: squared */
+            if (dist < bp->rule_1_distance && n != i) {            /* main.rs:475 */
+                cx = cx + pi[0];                                   /* main.rs:476 sum + boid_i_pos.to_vec() */
+                cy = cy + pi[1];
+                cz = cz + pi[2];
+                cnt = cnt + 1;
+            }
+        }
+        /* main.rs:482-492  flock_repel */
+        float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const float *pi = old_pos3 + 3 * (size_t)i;
+            const float dist = sqrtf(dist2_f32(pn, pi));           /* main.rs:485 distance */
+            if (dist < bp->rule_2_distance && n != i) {            /* main.rs:486 */
+                const float wx = pi[0] - pn[0], wy = pi[1] - pn[1], wz = pi[2] - pn[2];
+                rx = rx - wx;                                      /* main.rs:487 sum - (p_i - p_n) */
+                ry = ry - wy;
+                rz = rz - wz;
+            }
+        }
+        /* main.rs:494-504  (flock_match, vcount) over the velocity snapshot */
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        int32_t vcnt = 0;
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const float *vi = old_vel3 + 3 * (size_t)i;
+            const float dist = sqrtf(dist2_f32(v, vi));            /* main.rs:497 boid_n_vel.distance(*boid_i_vel) */
+            if (dist < bp->rule_3_distance && n != i) {            /* main.rs:498 */
+                mx = mx + vi[0];                                   /* main.rs:499 */
+                my = my + vi[1];
+                mz = mz + vi[2];
+                vcnt = vcnt + 1;
+            }
+        }
+        if (cnt > 0) { /* main.rs:506-508 */
+            const float c = (float)cnt;
+            cx = cx / c;
+            cy = cy / c;
+            cz = cz / c;
+        }
+        if (vcnt > 0) { /* main.rs:510-512 */
+            const float c = (float)vcnt;
+            mx = mx / c;
+            my = my / c;
+            mz = mz / c;
+        }
+        /* main.rs:514  vel = center*s1 + repel*s2 + match*s3   (left to right) */
+        float nvx = (cx * bp->rule_1_scale + rx * bp->rule_2_scale) + mx * bp->rule_3_scale;
+        float nvy = (cy * bp->rule_1_scale + ry * bp->rule_2_scale) + my * bp->rule_3_scale;
+        float nvz = (cz * bp->rule_1_scale + rz * bp->rule_2_scale) + mz * bp->rule_3_scale;
+        /* main.rs:516-518  speed clamp */
+        const float mag = sqrtf((nvx * nvx + nvy * nvy) + nvz * nvz);
+        if (mag > 1.0f) {
+            const float s = 1.0f / mag; /* normalize_to(1.0) = self * (1.0 / magnitude) */
+            nvx = nvx * s;
+            nvy = nvy * s;
+            nvz = nvz * s;
+        }
+        v[0] = nvx;
+        v[1] = nvy;
+        v[2] = nvz;
+        /* main.rs:521  pos = vel * dt + pos */
+        float *p = pos3_out + 3 * (size_t)l;
+        const float sx = nvx * bp->dt, sy = nvy * bp->dt, sz = nvz * bp->dt;
+        p[0] = sx + pn[0];
+        p[1] = sy + pn[1];
+        p[2] = sz + pn[2];
+        /* main.rs:522-524 */
+        if (inst16) instance_matrix(inst16 + 16 * (size_t)l, p, v);
+    }
+}
+
+typedef struct {
+    float *old_pos3, *old_vel3, *pos3, *vel3, *inst16;
+    uint32_t n, k, first, count;
+    const nbo_boids_params *bp;
+    int tid;
+    pthread_barrier_t *bar;
+} nbo_boids_job;
+
+static void *nbo_boids_worker(void *arg)
+{
+    nbo_boids_job *j = (nbo_boids_job *)arg;
+    for (uint32_t s = 0; s < j->k; ++s) {
+        if (j->tid == 0) { /* main.rs:459-460 */
+            memcpy(j->old_pos3, j->pos3, sizeof(float) * 3 * (size_t)j->n);
+            memcpy(j->old_vel3, j->vel3, sizeof(float) * 3 * (size_t)j->n);
+        }
+        if (j->bar) pthread_barrier_wait(j->bar);
+        float *inst = (j->inst16 && s + 1 == j->k) ? j->inst16 + 16 * (size_t)j->first : NULL;
+        nbo_boids_step_range(j->old_pos3, j->old_vel3, j->pos3 + 3 * (size_t)j->first, j->vel3 + 3 * (size_t)j->first, inst,
+                             j->n, j->first, j->count, j->bp);
+        if (j->bar) pthread_barrier_wait(j->bar);
+    }
+    return NULL;
+}
+
+/* update_instance_boids (main.rs:443-526) applied k times. */
+NBO_API int nbo_boids_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, const nbo_boids_params *bp,
+                          int nthreads)
+{
+    float *oldp = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    float *oldv = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    if (!oldp || !oldv) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n) nthreads = n ? (int)n : 1;
+    if (nthreads == 1) {
+        nbo_boids_job job = {oldp, oldv, pos3, vel3, inst16, n, k, 0, n, bp, 0, NULL};
+        nbo_boids_worker(&job);
+    } else {
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, NULL, (unsigned)nthreads);
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        nbo_boids_job *jobs = (nbo_boids_job *)malloc(sizeof(nbo_boids_job) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; ++t) {
+            uint32_t lo = (uint32_t)(((uint64_t)n * (uint64_t)t) / (uint64_t)nthreads);
+            uint32_t hi = (uint32_t)(((uint64_t)n * (uint64_t)(t + 1)) / (uint64_t)nthreads);
+            jobs[t] = (nbo_boids_job){oldp, oldv, pos3, vel3, inst16, n, k, lo, hi - lo, bp, t, &bar};
+            pthread_create(&th[t], NULL, nbo_boids_worker, &jobs[t]);
+        }
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&bar);
+        free(jobs);
+        free(th);
+    }
+    free(oldp);
+    free(oldv);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * binary64 variant of the same recurrence: NOT the reference's arithmetic -- it exists to
  * show the rounding-noise floor of the chaotic system (sixth finding).

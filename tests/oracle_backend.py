@@ -27,3 +27,15 @@ class OracleBackend:
     def instances(self, count, pos, vel, inst):
         m = oracle.instances(pos[:count, :3].contiguous().numpy(), vel[:count, :3].contiguous().numpy())
         inst[:count] = torch.from_numpy(m.reshape(count, 16))
+
+    def boids_step(self, params, n_total, first, count, pos_in, vel_in, pos_out, vel_out):
+        bp = oracle.boids_params()
+        for k in ("dt", "rule_1_distance", "rule_2_distance", "rule_3_distance", "rule_1_scale", "rule_2_scale", "rule_3_scale"):
+            setattr(bp, k, getattr(params, k))
+        op = pos_in[:n_total, :3].contiguous().numpy()
+        ov = vel_in[:n_total, :3].contiguous().numpy()
+        p_new, v_new = oracle.boids_step_range(op, ov, first, count, bp)
+        pos_out[first:first + count, :3] = torch.from_numpy(p_new)
+        pos_out[first:first + count, 3] = 0
+        vel_out[first:first + count, :3] = torch.from_numpy(v_new)
+        vel_out[first:first + count, 3] = 0

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, out_dir):
+def _worker(rank, world, port, n, k, out_dir, boids=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,7 +35,13 @@ def _worker(rank, world, port, n, k, out_dir):
         pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
         sc = nenbody_amd.ShardedScene(pos, vel, backend=OracleBackend(), device="cpu")
         assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank]
-        sc.step_n(k)
+        if boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
+            sc.step_boids()
+            sc.step()
+            for _ in range(k):
+                sc.step_boids()
+        else:
+            sc.step_n(k)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities(),
                  inst=sc.local_instances(), first=sc.first, count=sc.count)
     finally:
@@ -68,3 +74,18 @@ def test_world_of_one_needs_no_process_group(oracle):
     p_ref, v_ref = oracle.run(pos, vel, 3)
     assert (sc.positions().view(np.uint32) == p_ref.view(np.uint32)).all()
     assert (sc.velocities().view(np.uint32) == v_ref.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("world,n,k", [(2, 60, 2), (3, 41, 2)])
+def test_sharded_boids_equals_unsharded(tmp_path, oracle, world, n, k):
+    """Boids gathers positions AND velocities every step (main.rs:494-504 reads every old velocity)."""
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), True), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    p_ref, v_ref = oracle.run(p_ref, v_ref, 1)
+    p_ref, v_ref = oracle.boids_run(p_ref, v_ref, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert (got["pos"].view(np.uint32) == p_ref.view(np.uint32)).all()
+        assert (got["vel"].view(np.uint32) == v_ref.view(np.uint32)).all()

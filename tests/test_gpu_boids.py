@@ -1,0 +1,198 @@
+"""GPU parity tests of the boids controller (update_instance_boids, src/main.rs:443-526):
+the HIP kernel through the C ABI against the CPU oracle, bit for bit."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(got, ref, what=""):
+    g, r = bits(got), bits(ref)
+    assert (g == r).all(), f"{what}: {(g != r).sum()} of {g.size} words differ, first at {np.argwhere(g != r)[0]}"
+
+
+def cloud(oracle, n, seed, scale=0.3):
+    pos, vel = oracle.init_state(n, seed)
+    rng = np.random.default_rng(seed)
+    pos[:, 2] = rng.uniform(-100, 100, n).astype(np.float32)
+    vel[:, 2] = rng.uniform(0, 0.1, n).astype(np.float32)
+    return (pos * np.float32(scale)).astype(np.float32), vel
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 65, 255, 256, 257, 1000, 1025, 3000])
+def test_boids_ragged_sizes_bit_exact(nb, oracle, n):
+    pos, vel = cloud(oracle, n, seed=n)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(3)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 3)
+    assert_bits_equal(p, p_ref, f"positions n={n}")
+    assert_bits_equal(v, v_ref, f"velocities n={n}")
+
+
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_boids_every_tile_size(nb, oracle, tile):
+    pos, vel = cloud(oracle, 2500, seed=tile)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(2, nb.default_boids_params(tile=tile))
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 2)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_boids_reference_initial_state_long_run(nb, oracle):
+    """The reference's own planar initial distributions (main.rs:738-747), 100 steps: flocks form, speeds clamp."""
+    pos, vel = nb.init_state(1024, 1234)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(100)
+        p, v = sc.state()
+        inst = sc.instances()
+    p_ref, v_ref, inst_ref = oracle.boids_run(pos, vel, 100, want_instances=True)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    assert (p[:, 2] == 0).all()
+
+
+def test_boids_radius_boundaries_are_exact(nb, oracle):
+    """Pairs placed exactly at, just inside and just outside each radius: the squared-distance thresholds that replace
+    sqrt(d2) < r on the GPU must agree with the reference's sqrt test on every one of them."""
+    base = np.float32(5.0)
+    xs = [np.float32(0)]
+    x = base
+    for _ in range(6):
+        x = np.nextafter(x, np.float32(0))
+    for _ in range(13):                        # 6 floats below 5.0 ... 6 above
+        xs.append(x)
+        x = np.nextafter(x, np.float32(10))
+    r1 = np.float32(np.sqrt(1000.0))
+    x = r1
+    for _ in range(4):
+        x = np.nextafter(x, np.float32(0))
+    for _ in range(9):
+        xs.append(x)
+        x = np.nextafter(x, np.float32(100))
+    pos = np.zeros((len(xs), 3), np.float32)
+    pos[:, 0] = xs
+    pos[1::2, 1] = np.float32(1e-4)            # break ties: some pairs get a tiny y offset
+    vel = np.zeros_like(pos)
+    vel[:, 0] = np.linspace(0, 0.05, len(xs), dtype=np.float32)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(1)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    assert_bits_equal(v, v_ref)
+    assert_bits_equal(p, p_ref)
+
+
+def test_boids_velocity_radius_and_custom_constants(nb, oracle):
+    """A rule-3 radius small enough to cut (the default 500 never does) and other non-default constants."""
+    pos, vel = cloud(oracle, 800, seed=5)
+    vel *= np.float32(30)                      # velocity differences up to ~4
+    for r3, r2, r1 in [(1.0, 3.0, 400.0), (2.5, 0.0, 1e9), (np.inf, 7.5, 0.5), (0.5, -1.0, np.nan)]:
+        bp, obp = nb.default_boids_params(), oracle.boids_params()
+        for k, val in (("rule_3_distance", r3), ("rule_2_distance", r2), ("rule_1_distance", r1), ("dt", 0.1), ("rule_2_scale", 0.2)):
+            setattr(bp, k, val)
+            setattr(obp, k, val)
+        with nb.Scene(pos, vel) as sc:
+            sc.step_boids_n(2, bp)
+            p, v = sc.state()
+        p_ref, v_ref = oracle.boids_run(pos, vel, 2, obp)
+        assert_bits_equal(v, v_ref, f"r3={r3} r2={r2} r1={r1}")
+        assert_bits_equal(p, p_ref, f"r3={r3} r2={r2} r1={r1}")
+
+
+def test_boids_nonfinite_positions_like_the_reference(nb, oracle):
+    pos, vel = cloud(oracle, 300, seed=8)
+    pos[10, 0] = np.inf
+    pos[20, 1] = np.nan
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(1)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    assert (np.isnan(p) == np.isnan(p_ref)).all() and (np.isnan(v) == np.isnan(v_ref)).all()
+    ok = ~np.isnan(p_ref)
+    assert (bits(p)[ok] == bits(p_ref)[ok]).all()
+    okv = ~np.isnan(v_ref)
+    assert (bits(v)[okv] == bits(v_ref)[okv]).all()
+
+
+def test_boids_and_nbody_steps_mix(nb, oracle):
+    pos, vel = cloud(oracle, 600, seed=12)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(2)
+        sc.step_n(2)
+        sc.step_boids_n(1)
+        p, v = sc.state()
+    pr, vr = oracle.boids_run(pos, vel, 2)
+    pr, vr = oracle.run(pr, vr, 2)
+    pr, vr = oracle.boids_run(pr, vr, 1)
+    assert_bits_equal(p, pr)
+    assert_bits_equal(v, vr)
+
+
+def test_update_instance_boids_operator(nb, oracle):
+    n = 400
+    pos, vel = cloud(oracle, n, seed=21)
+    p_ref, v_ref, inst_ref = oracle.boids_run(pos, vel, 1, want_instances=True)
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n, 4, 4), np.float32)
+    nb.update_instance_boids(inst, positions, old_p, velocities, old_v)
+    assert_bits_equal(old_p, pos)            # main.rs:459
+    assert_bits_equal(old_v, vel)            # main.rs:460
+    assert_bits_equal(positions, p_ref)
+    assert_bits_equal(velocities, v_ref)
+    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        nb.update_instance_boids(inst, positions, np.zeros((n - 1, 3), np.float32), velocities, old_v)
+
+
+def test_boids_sharded_launch_equals_unsharded(nb, oracle):
+    """What each rank of a multi-GPU job runs: index ranges of one step, positions AND velocities written per range."""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    be = HipBackend()
+    n = 1500
+    pos, vel = cloud(oracle, n, seed=31)
+    dev = torch.device("cuda", 0)
+
+    def rec(a):
+        t = torch.zeros((n, 4), dtype=torch.float32)
+        t[:, :3] = torch.from_numpy(a)
+        return t.to(dev)
+
+    pin, vin = rec(pos), rec(vel)
+    pout, vout = torch.zeros_like(pin), torch.zeros_like(vin)
+    bp = nb.default_boids_params()
+    for first, count in [(0, 1), (1, 255), (256, 700), (956, 544)]:
+        be.boids_step(bp, n, first, count, pin, vin, pout, vout)
+    torch.cuda.synchronize()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    assert_bits_equal(pout[:, :3].cpu().numpy(), p_ref)
+    assert_bits_equal(vout[:, :3].cpu().numpy(), v_ref)
+
+
+def test_boids_full_size_sampled_vs_oracle(nb, oracle):
+    """N = 131 072 (BASELINE size): sampled bodies folded over all j by the oracle."""
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(1)
+        p, v = sc.state()
+    idx = np.unique(np.concatenate([np.arange(0, 16), np.arange(n - 16, n), np.linspace(16, n - 17, 64).astype(np.int64)]))
+    for i in idx:
+        p_ref, v_ref = oracle.boids_step_range(pos, vel, int(i), 1)
+        assert (bits(p[i]) == bits(p_ref[0])).all() and (bits(v[i]) == bits(v_ref[0])).all(), f"body {i}"
+    speed = np.sqrt((v.astype(np.float64) ** 2).sum(axis=1))
+    assert speed.max() <= 1.0 + 1e-6            # the clamp of main.rs:516-518

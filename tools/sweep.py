@@ -117,6 +117,21 @@ def main():
         return shard_sweep()
     if what == "lanes":
         return lanes_sweep()
+    if what == "boids":
+        for n in (16384, 131072):
+            for tile in (256, 512, 1024):
+                pos, vel = nb.init_state(n, 1234)
+                with nb.Scene(pos, vel) as sc:
+                    bp = nb.default_boids_params(tile=tile)
+                    sc.step_boids_n(2, bp)
+                    sc.sync()
+                    steps = 5 if n > 50000 else 20
+                    t0 = time.perf_counter()
+                    sc.step_boids_n(steps, bp)
+                    sc.sync()
+                    dt = (time.perf_counter() - t0) / steps
+                print(f"boids n={n} tile={tile} ms/step={dt * 1e3:.3f} body-updates/s={n / dt:.3e} pairs/s={float(n) * n / dt:.3e}", flush=True)
+        return
     if what == "pc":
         import torch
 
