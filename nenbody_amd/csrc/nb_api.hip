@@ -250,6 +250,13 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
     a.s1 = p.rule_1_scale;
     a.s2 = p.rule_2_scale;
     a.s3 = p.rule_3_scale;
+    if (n_total >= (1u << 24)) {
+        *err = "nb: boids: neighbour counts are kept in binary32 and need n_total < 2^24";
+        return NB_ERR_UNSUPPORTED;
+    }
+    uint32_t ff = 0;
+    env_u32("NB_BOIDS_FORCE", &ff);
+    a.force_flags = ff & 3u;
     *out = a;
     *tile = t;
     return NB_OK;

@@ -30,11 +30,12 @@ struct BoidsArgs {
     float r1;              // rule_1_distance, compared with the squared distance (main.rs:451, 474-475)
     float t2, t3;          // squared-distance thresholds equivalent to sqrt(d2) < rule_2_distance / rule_3_distance
     float s1, s2, s3;      // rule scales, main.rs:454-456
+    uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form (tests)
 };
 hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s);
 
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
-hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_JP_TU
+hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_NOSLP_TU
 hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s);  // producer/consumer form: 64 bodies x (2 + producers) waves per workgroup
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);

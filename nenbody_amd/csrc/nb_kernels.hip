@@ -288,7 +288,230 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
     }
 }
 
-#ifndef NBK_JP_TU
+#ifdef NBK_NOSLP_TU
+// ------------------------------------------------------------------------------------------------
+// Boids controller: update_instance_boids, main.rs:443-526 (SURVEY.md section 8f, rank 1).
+//
+// Three index-ordered, predicated folds per body over the snapshots of all positions / all velocities:
+//   rule 1 (main.rs:471-480)  centre += p_i, count += 1      if |p_i - p_n|^2      < rule_1_distance && i != n
+//   rule 2 (main.rs:482-492)  repel  -= (p_i - p_n)           if sqrt(|p_i - p_n|^2) < rule_2_distance && i != n
+//   rule 3 (main.rs:494-504)  match  += v_i, vcount += 1      if sqrt(|v_i - v_n|^2) < rule_3_distance && i != n
+// One lane per body, j in index order, so every sum sees the reference's sequence of additions.  The two sqrt
+// predicates are evaluated WITHOUT a sqrt: sqrt is monotonic and correctly rounded in the reference, so
+// `sqrt(x) < r` holds exactly for x <= T(r), T(r) = the largest binary32 whose correctly rounded root is below r;
+// nb_api computes T on the host (bisection over bit patterns with the host's IEEE sqrtf).  NaN fails every test on
+// both sides.  The epilogue (means, velocity blend, speed clamp, position update: main.rs:506-521) runs once per
+// body with the correctly rounded '/' and sqrt.
+//
+// Per-tile specialisations, all exact (chosen from flags the loaders compute while staging a tile):
+//   SELF    only the tile that contains the workgroup's own bodies tests `i != n`; elsewhere it is true by range.
+//   MASKED  every record of the tile finite: a skipped term is added as 0 * x through an FMA with a 0/1 mask --
+//           fma(1, x, s) == s + x and fma(0, x, s) == s for finite x (the sums never hold -0: they start at +0 and
+//           x + (-x) rounds to +0) -- one compare + one select per rule instead of a select per component.
+//           Non-finite records take the select-on-result form, which leaves a skipped sum untouched whatever x is.
+//   PLANAR  every z (positions and velocities, tile and own bodies) is +/-0: the z terms contribute +/-0 to the
+//           squared distances and leave the z sums at +0, so they are skipped (the reference's initial state is
+//           planar, main.rs:740,745, and stays planar).
+// This kernel lives in the SLP-off translation unit: packed math buys nothing here and its register shuffles cost 25 %.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBoidsNonFinite = 1u;  // some coordinate is inf/NaN -> select form
+constexpr uint32_t kBoidsNonPlanar = 2u;  // some z != 0 (position or velocity)
+
+__device__ __forceinline__ uint32_t boids_flags(const float4 p, const float4 v)
+{
+    auto nonfinite = [](float c) { return (__float_as_uint(c) & 0x7f800000u) == 0x7f800000u ? kBoidsNonFinite : 0u; };
+    auto nonzero = [](float c) { return (__float_as_uint(c) & 0x7fffffffu) != 0u ? kBoidsNonPlanar : 0u; };
+    return nonfinite(p.x) | nonfinite(p.y) | nonfinite(p.z) | nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonzero(p.z) |
+           nonzero(v.z);
+}
+
+struct BoidsAcc {
+    float cx, cy, cz, rx, ry, rz, mx, my, mz;  // main.rs:472, 483, 495: all start at Vector3::new(0.0, 0.0, 0.0)
+    float cnt, vcnt;                           // counts kept in binary32: exact below 2^24 (nb_api refuses larger sets)
+};
+
+template <bool SELF, bool MASKED, bool PLANAR>
+__device__ __forceinline__ void boids_pair(BoidsAcc &s, const float4 pj, const float4 vj, uint32_t j, uint32_t gn,
+                                           const float4 pn, const float4 vn, float r1, float t2, float t3)
+{
+    // keep .w "used": the records are then fetched with one ds_read_b128 each (4 LDS cycles) instead of ds_read_b96 (8)
+    asm volatile("" ::"v"(pj.w), "v"(vj.w));
+    const bool ne = SELF ? (j != gn) : true;                              // main.rs:475 n != i
+    const float dx = pj.x - pn.x, dy = pj.y - pn.y;                       // distance2: (other - self)
+    const float dz = PLANAR ? 0.f : pj.z - pn.z;
+    float d2 = (dx * dx) + (dy * dy);
+    if (!PLANAR) d2 = d2 + (dz * dz);
+    const bool p1 = (d2 < r1) && ne;                                      // main.rs:474-475 (squared distance)
+    const bool p2 = (d2 <= t2) && ne;                                     // main.rs:485-486  sqrt(d2) < rule_2_distance
+    const float ex = vj.x - vn.x, ey = vj.y - vn.y;
+    const float ez = PLANAR ? 0.f : vj.z - vn.z;
+    float e2 = (ex * ex) + (ey * ey);
+    if (!PLANAR) e2 = e2 + (ez * ez);
+    const bool p3 = (e2 <= t3) && ne;                                     // main.rs:497-498  sqrt(e2) < rule_3_distance
+    if (MASKED) {
+        const float m1 = p1 ? 1.f : 0.f, m2 = p2 ? -1.f : 0.f, m3 = p3 ? 1.f : 0.f;
+        s.cx = __builtin_fmaf(m1, pj.x, s.cx);                            // main.rs:476  sum + p_i
+        s.cy = __builtin_fmaf(m1, pj.y, s.cy);
+        if (!PLANAR) s.cz = __builtin_fmaf(m1, pj.z, s.cz);
+        s.cnt = s.cnt + m1;
+        s.rx = __builtin_fmaf(m2, dx, s.rx);                              // main.rs:487  sum - (p_i - p_n)
+        s.ry = __builtin_fmaf(m2, dy, s.ry);
+        if (!PLANAR) s.rz = __builtin_fmaf(m2, dz, s.rz);
+        s.mx = __builtin_fmaf(m3, vj.x, s.mx);                            // main.rs:499  sum + v_i
+        s.my = __builtin_fmaf(m3, vj.y, s.my);
+        if (!PLANAR) s.mz = __builtin_fmaf(m3, vj.z, s.mz);
+        s.vcnt = s.vcnt + m3;
+    } else {
+        const float c1x = s.cx + pj.x, c1y = s.cy + pj.y, c1z = s.cz + pj.z;
+        s.cx = p1 ? c1x : s.cx;
+        s.cy = p1 ? c1y : s.cy;
+        s.cz = p1 ? c1z : s.cz;
+        s.cnt = p1 ? s.cnt + 1.f : s.cnt;
+        const float r1x = s.rx - dx, r1y = s.ry - dy, r1z = s.rz - dz;
+        s.rx = p2 ? r1x : s.rx;
+        s.ry = p2 ? r1y : s.ry;
+        s.rz = p2 ? r1z : s.rz;
+        const float m1x = s.mx + vj.x, m1y = s.my + vj.y, m1z = s.mz + vj.z;
+        s.mx = p3 ? m1x : s.mx;
+        s.my = p3 ? m1y : s.my;
+        s.mz = p3 ? m1z : s.mz;
+        s.vcnt = p3 ? s.vcnt + 1.f : s.vcnt;
+    }
+}
+
+template <bool SELF, bool MASKED, bool PLANAR>
+__device__ __forceinline__ void boids_fold_tile(BoidsAcc &s, const float4 *tp, const float4 *tv, int nj, uint32_t j0, uint32_t gn,
+                                                const float4 pn, const float4 vn, float r1, float t2, float t3)
+{
+    int j = 0;
+    for (; j + 4 <= nj; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            boids_pair<SELF, MASKED, PLANAR>(s, tp[j + u], tv[j + u], j0 + (uint32_t)(j + u), gn, pn, vn, r1, t2, t3);
+    }
+    for (; j < nj; ++j) boids_pair<SELF, MASKED, PLANAR>(s, tp[j], tv[j], j0 + (uint32_t)j, gn, pn, vn, r1, t2, t3);
+}
+
+template <int TJ>
+__global__ __launch_bounds__(kBlock) void boids_step_kernel(BoidsArgs a)
+{
+    __shared__ float4 tile_p[2][TJ];
+    __shared__ float4 tile_v[2][TJ];
+    __shared__ uint32_t tile_flags[2][kWaves];
+    __shared__ uint32_t self_flags[kWaves];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + (uint32_t)tid;
+    const bool live = l < a.count;
+    const uint32_t gn = a.first + (live ? l : a.count - 1u);  // this body's global index n
+    const float4 pn = a.pos_in[gn];
+    const float4 vn = a.vel_in[gn];
+    auto wave_flags = [](uint32_t f) {
+        return (__any((int)(f & kBoidsNonFinite)) ? kBoidsNonFinite : 0u) | (__any((int)(f & kBoidsNonPlanar)) ? kBoidsNonPlanar : 0u);
+    };
+    {
+        const uint32_t f = wave_flags(boids_flags(pn, vn) | a.force_flags);
+        if ((tid & 63) == 0) self_flags[wave] = f;
+    }
+    // global index range of this workgroup's bodies: only tiles overlapping it can contain i == n
+    const uint32_t own_lo = a.first + blockIdx.x * (uint32_t)kBlock;
+    const uint32_t own_hi = own_lo + (uint32_t)kBlock;  // exclusive (past-the-shard indices never match a live body)
+
+    TileRegs<TJ> rp, rv;
+    const uint32_t n = a.n_total;
+    const uint32_t ntiles = (n + (uint32_t)TJ - 1u) / (uint32_t)TJ;
+    tile_fetch<TJ>(rp, a.pos_in, 0u, n, tid);
+    tile_fetch<TJ>(rv, a.vel_in, 0u, n, tid);
+    auto publish = [&](int buf) {
+        uint32_t f = 0;
+#pragma unroll
+        for (int k = 0; k < TJ / kBlock; ++k) {
+            f |= boids_flags(rp.r[k], rv.r[k]);
+            tile_p[buf][k * kBlock + tid] = rp.r[k];
+            tile_v[buf][k * kBlock + tid] = rv.r[k];
+        }
+        f = wave_flags(f);
+        if ((tid & 63) == 0) tile_flags[buf][wave] = f;
+    };
+    publish(0);
+    __syncthreads();
+    const uint32_t block_self = self_flags[0] | self_flags[1] | self_flags[2] | self_flags[3];
+
+    BoidsAcc s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1u) < ntiles;
+        if (more) {
+            tile_fetch<TJ>(rp, a.pos_in, (t + 1u) * (uint32_t)TJ, n, tid);
+            tile_fetch<TJ>(rv, a.vel_in, (t + 1u) * (uint32_t)TJ, n, tid);
+        }
+        const uint32_t j0 = t * (uint32_t)TJ;
+        const uint32_t left = n - j0;
+        const int nj = left < (uint32_t)TJ ? (int)left : TJ;
+        const uint32_t f = block_self | tile_flags[buf][0] | tile_flags[buf][1] | tile_flags[buf][2] | tile_flags[buf][3];
+        const bool has_self = j0 < own_hi && j0 + (uint32_t)nj > own_lo;
+        const float4 *tp = tile_p[buf], *tv = tile_v[buf];
+        if (has_self || (f & kBoidsNonFinite))
+            boids_fold_tile<true, false, false>(s, tp, tv, nj, j0, gn, pn, vn, a.r1, a.t2, a.t3);
+        else if (f & kBoidsNonPlanar)
+            boids_fold_tile<false, true, false>(s, tp, tv, nj, j0, gn, pn, vn, a.r1, a.t2, a.t3);
+        else
+            boids_fold_tile<false, true, true>(s, tp, tv, nj, j0, gn, pn, vn, a.r1, a.t2, a.t3);
+        if (more) publish(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (live) {
+        float cx = s.cx, cy = s.cy, cz = s.cz, mx = s.mx, my = s.my, mz = s.mz;
+        if (s.cnt > 0.f) {  // main.rs:506-508  (count as f32)
+            cx = cx / s.cnt;
+            cy = cy / s.cnt;
+            cz = cz / s.cnt;
+        }
+        if (s.vcnt > 0.f) {  // main.rs:510-512
+            mx = mx / s.vcnt;
+            my = my / s.vcnt;
+            mz = mz / s.vcnt;
+        }
+        // main.rs:514  vel = center*s1 + repel*s2 + match*s3, left to right, every product and sum rounded
+        const float ax = cx * a.s1, ay = cy * a.s1, az = cz * a.s1;
+        const float bx = s.rx * a.s2, by = s.ry * a.s2, bz = s.rz * a.s2;
+        const float gx = mx * a.s3, gy = my * a.s3, gz = mz * a.s3;
+        float vx = (ax + bx) + gx, vy = (ay + by) + gy, vz = (az + bz) + gz;
+        // main.rs:516-518  |vel| > 1 -> vel * (1 / |vel|).  __builtin_sqrtf is correctly rounded under
+        // -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn is NOT: it is the 1-ulp v_sqrt_f32).
+        const float q0 = vx * vx, q1 = vy * vy, q2 = vz * vz;
+        const float mag = __builtin_sqrtf((q0 + q1) + q2);
+        if (mag > 1.0f) {
+            const float sc = 1.0f / mag;
+            vx = vx * sc;
+            vy = vy * sc;
+            vz = vz * sc;
+        }
+        // main.rs:521  pos = vel * dt + pos
+        const float sx = vx * a.dt, sy = vy * a.dt, sz = vz * a.dt;
+        a.vel_out[a.first + l] = make_float4(vx, vy, vz, 0.f);
+        a.pos_out[a.first + l] = make_float4(sx + pn.x, sy + pn.y, sz + pn.z, 0.f);
+    }
+}
+
+hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s)
+{
+    const dim3 grid(ceil_div_u(a.count, kBlock)), block(kBlock);
+    switch (tile) {
+        case 256: hipLaunchKernelGGL(boids_step_kernel<256>, grid, block, 0, s, a); break;
+        case 512: hipLaunchKernelGGL(boids_step_kernel<512>, grid, block, 0, s, a); break;
+        case 1024: hipLaunchKernelGGL(boids_step_kernel<1024>, grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+#endif  // NBK_NOSLP_TU
+
+#ifndef NBK_NOSLP_TU
 // ------------------------------------------------------------------------------------------------
 // STRICT, producer/consumer form ("pc"): the same arithmetic and the same summation order, for shards too small
 // to fill the chip with one lane per body.
@@ -642,144 +865,6 @@ __global__ __launch_bounds__(kBlock) void integrate_partials_kernel(StepArgs a, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Boids controller: update_instance_boids, main.rs:443-526 (SURVEY.md section 8f, rank 1).
-//
-// Three index-ordered, predicated folds per body over the snapshots of all positions / all velocities:
-//   rule 1 (main.rs:471-480)  centre += p_i, count += 1      if |p_i - p_n|^2      < rule_1_distance && i != n
-//   rule 2 (main.rs:482-492)  repel  -= (p_i - p_n)           if sqrt(|p_i - p_n|^2) < rule_2_distance && i != n
-//   rule 3 (main.rs:494-504)  match  += v_i, vcount += 1      if sqrt(|v_i - v_n|^2) < rule_3_distance && i != n
-// One lane per body, j in index order, so every sum sees the reference's sequence of additions.  The two sqrt
-// predicates are evaluated WITHOUT a sqrt: sqrt is monotonic and correctly rounded in the reference, so
-// `sqrt(x) < r` holds exactly for x <= T(r), T(r) = the largest binary32 whose correctly rounded root is below r;
-// nb_api computes T on the host (bisection over bit patterns with the host's IEEE sqrtf).  NaN fails every test on
-// both sides.  A skipped term leaves the sum untouched (select on the result, not on the operand: -0 survives).
-// The epilogue (means, velocity blend, speed clamp, position update: main.rs:506-521) runs once per body with the
-// correctly rounded '/' and sqrt.
-// ------------------------------------------------------------------------------------------------
-template <int TJ>
-__global__ __launch_bounds__(kBlock) void boids_step_kernel(BoidsArgs a)
-{
-    __shared__ float4 tile_p[2][TJ];
-    __shared__ float4 tile_v[2][TJ];
-
-    const int tid = threadIdx.x;
-    const uint32_t l = blockIdx.x * (uint32_t)kBlock + (uint32_t)tid;
-    const bool live = l < a.count;
-    const uint32_t gn = a.first + (live ? l : a.count - 1u);  // this body's global index n
-    const float4 pn = a.pos_in[gn];
-    const float4 vn = a.vel_in[gn];
-
-    TileRegs<TJ> rp, rv;
-    const uint32_t n = a.n_total;
-    const uint32_t ntiles = (n + (uint32_t)TJ - 1u) / (uint32_t)TJ;
-    tile_fetch<TJ>(rp, a.pos_in, 0u, n, tid);
-    tile_fetch<TJ>(rv, a.vel_in, 0u, n, tid);
-    auto publish = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < TJ / kBlock; ++k) {
-            tile_p[buf][k * kBlock + tid] = rp.r[k];
-            tile_v[buf][k * kBlock + tid] = rv.r[k];
-        }
-    };
-    publish(0);
-    __syncthreads();
-
-    float cx = 0.f, cy = 0.f, cz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;
-    int cnt = 0, vcnt = 0;
-    auto pair = [&](const float4 pj, const float4 vj, uint32_t j) {
-        const bool ne = j != gn;                                       // main.rs:475 n != i
-        const float dx = pj.x - pn.x, dy = pj.y - pn.y, dz = pj.z - pn.z;  // distance2: (other - self)
-        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-        const float d2 = (xx + yy) + zz;
-        const bool p1 = (d2 < a.r1) && ne;                              // main.rs:474-475 (squared distance)
-        const float c1x = cx + pj.x, c1y = cy + pj.y, c1z = cz + pj.z;  // main.rs:476
-        cx = p1 ? c1x : cx;
-        cy = p1 ? c1y : cy;
-        cz = p1 ? c1z : cz;
-        cnt += p1 ? 1 : 0;
-        const bool p2 = (d2 <= a.t2) && ne;                             // main.rs:485-486  sqrt(d2) < rule_2_distance
-        const float r1x = rx - dx, r1y = ry - dy, r1z = rz - dz;        // main.rs:487  sum - (p_i - p_n)
-        rx = p2 ? r1x : rx;
-        ry = p2 ? r1y : ry;
-        rz = p2 ? r1z : rz;
-        const float ex = vj.x - vn.x, ey = vj.y - vn.y, ez = vj.z - vn.z;
-        const float e2 = ((ex * ex) + (ey * ey)) + (ez * ez);
-        const bool p3 = (e2 <= a.t3) && ne;                             // main.rs:497-498  sqrt(e2) < rule_3_distance
-        const float m1x = mx + vj.x, m1y = my + vj.y, m1z = mz + vj.z;  // main.rs:499
-        mx = p3 ? m1x : mx;
-        my = p3 ? m1y : my;
-        mz = p3 ? m1z : mz;
-        vcnt += p3 ? 1 : 0;
-    };
-
-    int buf = 0;
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const bool more = (t + 1u) < ntiles;
-        if (more) {
-            tile_fetch<TJ>(rp, a.pos_in, (t + 1u) * (uint32_t)TJ, n, tid);
-            tile_fetch<TJ>(rv, a.vel_in, (t + 1u) * (uint32_t)TJ, n, tid);
-        }
-        const uint32_t j0 = t * (uint32_t)TJ;
-        const uint32_t left = n - j0;
-        const int nj = left < (uint32_t)TJ ? (int)left : TJ;
-        int j = 0;
-        for (; j + 4 <= nj; j += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pair(tile_p[buf][j + u], tile_v[buf][j + u], j0 + (uint32_t)(j + u));
-        }
-        for (; j < nj; ++j) pair(tile_p[buf][j], tile_v[buf][j], j0 + (uint32_t)j);
-        if (more) publish(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    if (live) {
-        if (cnt > 0) {  // main.rs:506-508
-            const float c = (float)cnt;
-            cx = cx / c;
-            cy = cy / c;
-            cz = cz / c;
-        }
-        if (vcnt > 0) {  // main.rs:510-512
-            const float c = (float)vcnt;
-            mx = mx / c;
-            my = my / c;
-            mz = mz / c;
-        }
-        // main.rs:514  vel = center*s1 + repel*s2 + match*s3, left to right, every product and sum rounded
-        const float ax = cx * a.s1, ay = cy * a.s1, az = cz * a.s1;
-        const float bx = rx * a.s2, by = ry * a.s2, bz = rz * a.s2;
-        const float gx = mx * a.s3, gy = my * a.s3, gz = mz * a.s3;
-        float vx = (ax + bx) + gx, vy = (ay + by) + gy, vz = (az + bz) + gz;
-        // main.rs:516-518  |vel| > 1 -> vel * (1 / |vel|)
-        const float q0 = vx * vx, q1 = vy * vy, q2 = vz * vz;
-        const float mag = __builtin_sqrtf((q0 + q1) + q2);  // correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt (NOT __fsqrt_rn: that is the 1-ulp v_sqrt_f32)
-        if (mag > 1.0f) {
-            const float sc = 1.0f / mag;
-            vx = vx * sc;
-            vy = vy * sc;
-            vz = vz * sc;
-        }
-        // main.rs:521  pos = vel * dt + pos
-        const float sx = vx * a.dt, sy = vy * a.dt, sz = vz * a.dt;
-        a.vel_out[a.first + l] = make_float4(vx, vy, vz, 0.f);
-        a.pos_out[a.first + l] = make_float4(sx + pn.x, sy + pn.y, sz + pn.z, 0.f);
-    }
-}
-
-hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s)
-{
-    const dim3 grid(ceil_div_u(a.count, kBlock)), block(kBlock);
-    switch (tile) {
-        case 256: hipLaunchKernelGGL(boids_step_kernel<256>, grid, block, 0, s, a); break;
-        case 512: hipLaunchKernelGGL(boids_step_kernel<512>, grid, block, 0, s, a); break;
-        case 1024: hipLaunchKernelGGL(boids_step_kernel<1024>, grid, block, 0, s, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // model matrices, main.rs:437-439:  M = from_translation(p) * from_angle_z(atan2(v.y, v.x)), evaluated as
 // the explicit column-by-column product cgmath performs (so signed zeros and non-finite positions come
 // out the way they do in the reference).  atan2f/sinf/cosf are the device libm's: within a few ulp of
@@ -829,7 +914,7 @@ __global__ __launch_bounds__(kBlock) void unpack_kernel(uint32_t count, const fl
     xyz[3 * (size_t)l + 2] = r.z;
 }
 
-#endif  // !NBK_JP_TU
+#endif  // !NBK_NOSLP_TU
 
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
@@ -846,8 +931,8 @@ static hipError_t launch_strict_t(const StepArgs &a, hipStream_t s)
 #define NBK_CASE(T, U_, S_) \
     if (tile == T && unroll == U_ && lanes == S_) return launch_strict_t<T, U_, S_>(a, s)
 
-#ifdef NBK_JP_TU
-// This translation unit is the same source compiled with -DNBK_JP_TU -fno-slp-vectorize: it holds only the
+#ifdef NBK_NOSLP_TU
+// This translation unit is the same source compiled with -DNBK_NOSLP_TU -fno-slp-vectorize: it holds only the
 // j-parallel STRICT shapes (S > 1).  Without SLP the x/y running-sum adds stay scalar v_add_f32, so the row_shl DPP
 // fetch folds into them (v_add_f32_dpp); packed v_pk_add_f32 cannot take a DPP operand and would need a mov per term.
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s)
@@ -894,7 +979,7 @@ hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint
 #endif
 #undef NBK_CASE
 
-#ifndef NBK_JP_TU
+#ifndef NBK_NOSLP_TU
 template <int TJ, int IB>
 static hipError_t launch_fast_t(const StepArgs &a, uint32_t slices, hipStream_t s)
 {
@@ -940,6 +1025,6 @@ hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStrea
     return hipGetLastError();
 }
 
-#endif  // !NBK_JP_TU
+#endif  // !NBK_NOSLP_TU
 
 }  // namespace nbk

@@ -26,8 +26,16 @@ def cloud(oracle, n, seed, scale=0.3):
     return (pos * np.float32(scale)).astype(np.float32), vel
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "select", "masked3d", "select3d"])
+def force(request, monkeypatch):
+    """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form.
+    Every arithmetic form must give the same bits."""
+    monkeypatch.setenv("NB_BOIDS_FORCE", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 64, 65, 255, 256, 257, 1000, 1025, 3000])
-def test_boids_ragged_sizes_bit_exact(nb, oracle, n):
+def test_boids_ragged_sizes_bit_exact(nb, oracle, force, n):
     pos, vel = cloud(oracle, n, seed=n)
     with nb.Scene(pos, vel) as sc:
         sc.step_boids_n(3)
@@ -46,6 +54,38 @@ def test_boids_every_tile_size(nb, oracle, tile):
     p_ref, v_ref = oracle.boids_run(pos, vel, 2)
     assert_bits_equal(p, p_ref)
     assert_bits_equal(v, v_ref)
+
+
+@pytest.mark.parametrize("n", [7, 700, 2600])
+def test_boids_planar_state_every_form(nb, oracle, force, n):
+    """z = 0, vz = 0 (the reference's initial state): planar shortcut on/off, masked/select forms -- same bits."""
+    pos, vel = oracle.init_state(n, seed=n + 3)
+    pos *= np.float32(0.2)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(4)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 4)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_boids_mixed_tiles(nb, oracle):
+    """Some tiles planar, some not, one with a non-finite record: every tile picks its own form."""
+    n = 2600
+    pos, vel = oracle.init_state(n, seed=99)
+    pos *= np.float32(0.2)
+    pos[300:500, 2] = np.linspace(-3, 3, 200, dtype=np.float32)
+    vel[1500:1600, 2] = np.float32(0.05)
+    pos[2000, 0] = np.inf
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(2)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 2)
+    assert (np.isnan(p) == np.isnan(p_ref)).all() and (np.isnan(v) == np.isnan(v_ref)).all()
+    ok = ~np.isnan(p_ref)
+    assert (bits(p)[ok] == bits(p_ref)[ok]).all()
+    okv = ~np.isnan(v_ref)
+    assert (bits(v)[okv] == bits(v_ref)[okv]).all()
 
 
 def test_boids_reference_initial_state_long_run(nb, oracle):
