@@ -126,6 +126,31 @@ def main():
         other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
         other = time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel)
 
+    # Informational: the boids controller (update_instance_boids, main.rs:443-526), same set
+    # and sharding.  Never the headline; a failure here must not cost the n-body line.
+    boids = None
+    try:
+        sc = nb.ShardedScene(pos, vel)
+        for _ in range(2):
+            sc.step_boids()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        bsteps = max(2, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(bsteps):
+            sc.step_boids()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
+        if world > 1:
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        boids = {"metric": "body-updates/s, update_instance_boids (bit-exact)", "value": n * bsteps / float(bt.item()),
+                 "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
+    except Exception as e:  # pragma: no cover
+        boids = {"error": repr(e)}
+
     def summarise(r):
         steps_per_s = args.steps / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
@@ -166,6 +191,7 @@ def main():
             o = summarise(other)
             line["other_mode"] = {"mode": "fast" if primary == nb.NB_MODE_STRICT else "strict",
                                   "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
+        line["boids_controller"] = boids
         if world == 1 and not args.no_cpu_baseline:
             import oracle  # cpu_baseline leg: the oracle is timed here, never used by the product path
 

@@ -1,9 +1,11 @@
 /*
  * nenbody.h -- C ABI of libnenbody_hip.so: nenbody's all-pairs gravity + Euler step on MI355X (gfx950).
  *
- * This is the drop-in boundary for ONE path of Dasch0/nenbody: `update_instance_nbody`
- * (reference src/main.rs:404-441), the body of the `Scene::step()` the reference's empty
- * `src/scene.rs` (src/scene.rs:1, declared at src/main.rs:2) was evidently meant to hold.
+ * This is the drop-in boundary for the per-frame simulation update of Dasch0/nenbody: `update_instance_nbody`
+ * (reference src/main.rs:404-441) -- the path this library exists for -- and, as the first row beyond it, the
+ * controller the binary actually runs, `update_instance_boids` (src/main.rs:443-526).  Both are bodies of the
+ * `Scene::step()` the reference's empty `src/scene.rs` (src/scene.rs:1, declared at src/main.rs:2) was evidently
+ * meant to hold.
  * The reference has no FFI of its own; each entry point below cites the reference
  * interface it stands in for.  INTEGRATION.md shows the Rust `extern "C"` block and the
  * `Scene` shim a maintainer would add.
@@ -118,6 +120,23 @@ void nb_boids_default_params(nb_boids_params *p);
  * sqrt-based radius tests are evaluated exactly).  params == NULL -> defaults.  May be mixed freely with nb_step. */
 int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *params);
 
+/* k applications of the random-walk controller update_instance_random (src/main.rs:381-402): vel += (U[-1e-4,1e-4),
+ * U[-1e-4,1e-4), 0); pos += vel.  The reference draws from an unseeded thread_rng, so only the distribution is kept:
+ * the stream here is counter based on (seed, step index since nb_upload, body index). */
+int nb_step_random(nb_ctx *ctx, uint32_t k, uint64_t seed);
+
+/* Device-resident hand-off: pointers to the context's CURRENT device buffers -- 16-byte position
+ * and velocity records and, when inst is non-NULL, the model matrices of the current state (16 floats per body,
+ * produced now on the context's stream) -- for a consumer that reads them on the GPU instead of through nb_download
+ * (the reference re-uploads instance_data every frame, src/main.rs:932-936).  Valid until the next nb_step*, nb_upload
+ * or nb_destroy on ctx; call nb_sync first if the consumer does not run on a stream ordered after ctx's. */
+int nb_device_state(nb_ctx *ctx, const void **pos_rec, const void **vel_rec, const void **inst_16n);
+
+/* CameraArray::update (src/gfx.rs:397-408, build_camera :358-369) for the context's current state: per body
+ * out = cp * look_at_dir(eye = position, dir = velocity, up), where cp16 = OPENGL_TO_WGPU_MATRIX * perspective(...) is the
+ * array's constant (16 floats, column-major; the caller's cgmath::perspective keeps its tan()).  out_16n: host, 16n floats. */
+int nb_cameras(nb_ctx *ctx, const float *up_xyz, const float *cp16, float *out_16n);
+
 /* Device -> host, after waiting for queued steps.  Any of the three may be NULL.
  * inst_16n, when given, receives the model matrices of the current state (src/main.rs:437-439),
  * produced on demand by a separate kernel: they never feed back into the dynamics. */
@@ -155,6 +174,14 @@ int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_total, uint32
 
 /* Model matrices (main.rs:437-439) for `count` bodies: pos, vel -> inst (16 floats per body). */
 int nb_launch_instances(uint32_t count, const void *pos, const void *vel, void *inst_16n, void *stream);
+
+/* Camera matrices (gfx.rs:397-408) for `count` entities on caller-owned device memory: eyes/dirs are 16-byte records,
+ * out receives 16 floats per entity. */
+int nb_launch_cameras(uint32_t count, const void *eyes, const void *dirs, const float *up_xyz, const float *cp16, void *out_16n,
+                      void *stream);
+
+/* One random-walk step (main.rs:381-402) in place for `count` bodies whose global indices start at `first`. */
+int nb_launch_random_step(uint32_t first, uint32_t count, void *pos, void *vel, uint64_t seed, uint64_t step, void *stream);
 
 /* Stride-3 <-> 16-byte record conversion on the device. */
 int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream);

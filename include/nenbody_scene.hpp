@@ -68,6 +68,13 @@ public:
     }
     // k steps, device-resident, no download
     void step_n(uint32_t k) { check(nb_step(ctx_, k), ctx_); }
+    // one update_instance_boids (src/main.rs:443-526), reference constants unless given; host mirrors refreshed
+    void step_boids(const nb_boids_params *params = nullptr)
+    {
+        check(nb_step_boids(ctx_, 1, params), ctx_);
+        check(nb_download(ctx_, positions[0].data(), velocities[0].data(), instances[0][0].data()), ctx_);
+    }
+    void step_boids_n(uint32_t k, const nb_boids_params *params = nullptr) { check(nb_step_boids(ctx_, k, params), ctx_); }
     void sync() { check(nb_sync(ctx_), ctx_); }
     void refresh() { check(nb_download(ctx_, positions[0].data(), velocities[0].data(), instances[0][0].data()), ctx_); }
     uint64_t steps_done() const { return nb_steps_done(ctx_); }

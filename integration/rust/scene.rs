@@ -21,6 +21,19 @@ pub struct NbParams {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct NbBoidsParams {
+    pub dt: f32,              // src/main.rs:450
+    pub rule_1_distance: f32, // src/main.rs:451 (squared-distance radius)
+    pub rule_2_distance: f32, // src/main.rs:452
+    pub rule_3_distance: f32, // src/main.rs:453 (velocity space)
+    pub rule_1_scale: f32,    // src/main.rs:454
+    pub rule_2_scale: f32,    // src/main.rs:455
+    pub rule_3_scale: f32,    // src/main.rs:456
+    pub tile: u32,
+}
+
+#[repr(C)]
 pub struct NbCtx {
     _private: [u8; 0],
 }
@@ -34,6 +47,7 @@ extern "C" {
     fn nb_destroy(ctx: *mut NbCtx);
     fn nb_upload(ctx: *mut NbCtx, pos_xyz: *const f32, vel_xyz: *const f32) -> c_int;
     fn nb_step(ctx: *mut NbCtx, k: u32) -> c_int;
+    fn nb_step_boids(ctx: *mut NbCtx, k: u32, params: *const NbBoidsParams) -> c_int; // null = reference constants
     fn nb_download(ctx: *mut NbCtx, pos_xyz: *mut f32, vel_xyz: *mut f32, inst_16n: *mut f32) -> c_int;
     fn nb_sync(ctx: *mut NbCtx) -> c_int;
 }
@@ -99,6 +113,22 @@ impl Scene {
     /// src/main.rs:932-945 work unchanged.
     pub fn step(&mut self) -> Result<(), SceneError> {
         check(unsafe { nb_step(self.ctx, 1) }, self.ctx)?;
+        check(
+            unsafe {
+                nb_download(
+                    self.ctx,
+                    self.positions.as_mut_ptr() as *mut f32,
+                    self.velocities.as_mut_ptr() as *mut f32,
+                    self.instances.as_mut_ptr() as *mut f32,
+                )
+            },
+            self.ctx,
+        )
+    }
+
+    /// One `update_instance_boids` (src/main.rs:443-526) with the reference's constants; host mirrors refreshed.
+    pub fn step_boids(&mut self) -> Result<(), SceneError> {
+        check(unsafe { nb_step_boids(self.ctx, 1, std::ptr::null()) }, self.ctx)?;
         check(
             unsafe {
                 nb_download(

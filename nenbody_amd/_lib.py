@@ -77,6 +77,11 @@ PROTOTYPES = {
     "nb_step_boids": (c_int, [c_void_p, c_uint32, POINTER(NbBoidsParams)]),
     "nb_launch_boids_step": (
         c_int, [POINTER(NbBoidsParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_step_random": (c_int, [c_void_p, c_uint32, c_uint64]),
+    "nb_device_state": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "nb_cameras": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_launch_cameras": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),

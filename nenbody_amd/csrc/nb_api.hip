@@ -291,6 +291,7 @@ struct nb_ctx {
     float4 *vel_alt = nullptr;  // second velocity buffer: boids reads every old velocity, so velocities ping-pong too
     float *stage = nullptr;   // 3n floats: stride-3 staging for upload/download
     float4 *inst = nullptr;   // 4n float4, allocated on first use
+    float4 *cams = nullptr;   // 4n float4, allocated on first use (nb_cameras)
     void *scratch = nullptr;
     int cur = 0;
     bool uploaded = false;
@@ -363,6 +364,7 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     if (ctx->vel_alt) (void)hipFree(ctx->vel_alt);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->inst) (void)hipFree(ctx->inst);
+    if (ctx->cams) (void)hipFree(ctx->cams);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -510,6 +512,64 @@ NB_EXPORT int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *para
     return NB_OK;
 }
 
+NB_EXPORT int nb_step_random(nb_ctx *ctx, uint32_t k, uint64_t seed)
+{
+    if (!ctx) {
+        g_tls_error = "nb_step_random: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_step_random: no state uploaded (call nb_upload first)";
+        return NB_ERR_STATE;
+    }
+    for (uint32_t s = 0; s < k; ++s) {
+        NB_HIP(ctx, nbk::launch_random(0, ctx->n, ctx->pos[ctx->cur], ctx->vel, seed, ctx->steps, ctx->stream));
+        ctx->steps++;
+    }
+    return NB_OK;
+}
+
+NB_EXPORT int nb_device_state(nb_ctx *ctx, const void **pos_rec, const void **vel_rec, const void **inst_16n)
+{
+    if (!ctx) {
+        g_tls_error = "nb_device_state: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_device_state: no state uploaded";
+        return NB_ERR_STATE;
+    }
+    if (inst_16n) {
+        if (!ctx->inst) NB_HIP(ctx, hipMalloc((void **)&ctx->inst, (size_t)ctx->n * 16 * sizeof(float)));
+        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream));
+        *inst_16n = ctx->inst;
+    }
+    if (pos_rec) *pos_rec = ctx->pos[ctx->cur];
+    if (vel_rec) *vel_rec = ctx->vel;
+    return NB_OK;
+}
+
+NB_EXPORT int nb_cameras(nb_ctx *ctx, const float *up_xyz, const float *cp16, float *out_16n)
+{
+    if (!ctx) {
+        g_tls_error = "nb_cameras: ctx is null";
+        return NB_ERR_INVALID;
+    }
+    if (!up_xyz || !cp16 || !out_16n) {
+        ctx->err = "nb_cameras: null argument";
+        return NB_ERR_INVALID;
+    }
+    if (!ctx->uploaded) {
+        ctx->err = "nb_cameras: no state uploaded";
+        return NB_ERR_STATE;
+    }
+    if (!ctx->cams) NB_HIP(ctx, hipMalloc((void **)&ctx->cams, (size_t)ctx->n * 16 * sizeof(float)));
+    NB_HIP(ctx, nbk::launch_cameras(ctx->n, ctx->pos[ctx->cur], ctx->vel, up_xyz, cp16, ctx->cams, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(out_16n, ctx->cams, (size_t)ctx->n * 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NB_OK;
+}
+
 NB_EXPORT int nb_sync(nb_ctx *ctx)
 {
     if (!ctx) {
@@ -647,6 +707,26 @@ NB_EXPORT int nb_launch_instances(uint32_t count, const void *pos, const void *v
         return NB_ERR_INVALID;
     }
     NB_LAUNCH_TLS(nbk::launch_instances(count, (const float4 *)pos, (const float4 *)vel, (float4 *)inst_16n, (hipStream_t)stream));
+}
+
+NB_EXPORT int nb_launch_cameras(uint32_t count, const void *eyes, const void *dirs, const float *up_xyz, const float *cp16,
+                                void *out_16n, void *stream)
+{
+    if (!count || !eyes || !dirs || !up_xyz || !cp16 || !out_16n) {
+        g_tls_error = "nb_launch_cameras: bad argument";
+        return NB_ERR_INVALID;
+    }
+    NB_LAUNCH_TLS(nbk::launch_cameras(count, (const float4 *)eyes, (const float4 *)dirs, up_xyz, cp16, (float4 *)out_16n,
+                                      (hipStream_t)stream));
+}
+
+NB_EXPORT int nb_launch_random_step(uint32_t first, uint32_t count, void *pos, void *vel, uint64_t seed, uint64_t step, void *stream)
+{
+    if (!count || !pos || !vel) {
+        g_tls_error = "nb_launch_random_step: bad argument";
+        return NB_ERR_INVALID;
+    }
+    NB_LAUNCH_TLS(nbk::launch_random(first, count, (float4 *)pos, (float4 *)vel, seed, step, (hipStream_t)stream));
 }
 
 NB_EXPORT int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream)

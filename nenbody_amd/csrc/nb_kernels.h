@@ -39,6 +39,9 @@ hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, u
 hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s);  // producer/consumer form: 64 bodies x (2 + producers) waves per workgroup
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
+hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,
+                          hipStream_t s);
+hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *vel, uint64_t seed, uint64_t step, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 

@@ -896,6 +896,110 @@ __global__ __launch_bounds__(kBlock) void instances_kernel(uint32_t count, const
     for (int k = 0; k < 4; ++k) out[k] = make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// CameraArray::update, gfx.rs:397-408 / build_camera gfx.rs:358-369: one thread per
+// entity, M = CP * look_at_dir(eye, dir, up) with CP = correction * proj passed in by the caller (a constant of the
+// array).  normalize() = self * (1 / magnitude) with the correctly rounded sqrt and '/'.  Bit-identical to the oracle.
+// ------------------------------------------------------------------------------------------------
+struct Mat4Arg {
+    float m[16];  // column-major
+};
+
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+    const float q0 = x * x, q1 = y * y, q2 = z * z;
+    const float mag = __builtin_sqrtf((q0 + q1) + q2);
+    const float s = 1.0f / mag;
+    x = x * s;
+    y = y * s;
+    z = z * s;
+}
+
+__global__ __launch_bounds__(kBlock) void cameras_kernel(uint32_t count, const float4 *__restrict__ eyes,
+                                                         const float4 *__restrict__ dirs, float ux, float uy, float uz, Mat4Arg cp,
+                                                         float4 *__restrict__ out)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= count) return;
+    const float4 e = eyes[l];
+    const float4 d = dirs[l];
+    float fx = d.x, fy = d.y, fz = d.z;
+    normalize3(fx, fy, fz);                                   // f = dir.normalize()
+    const float a0 = fy * uz, a1 = fz * uy, b0 = fz * ux, b1 = fx * uz, c0 = fx * uy, c1 = fy * ux;
+    float sx = a0 - a1, sy = b0 - b1, sz = c0 - c1;           // s = f.cross(up)
+    normalize3(sx, sy, sz);
+    const float g0 = sy * fz, g1 = sz * fy, h0 = sz * fx, h1 = sx * fz, i0 = sx * fy, i1 = sy * fx;
+    const float wx = g0 - g1, wy = h0 - h1, wz = i0 - i1;     // u = s.cross(f)
+    const float es0 = e.x * sx, es1 = e.y * sy, es2 = e.z * sz;
+    const float eu0 = e.x * wx, eu1 = e.y * wy, eu2 = e.z * wz;
+    const float ef0 = e.x * fx, ef1 = e.y * fy, ef2 = e.z * fz;
+    const float es = (es0 + es1) + es2, eu = (eu0 + eu1) + eu2, ef = (ef0 + ef1) + ef2;
+    const float view[4][4] = {{sx, wx, -fx, 0.f}, {sy, wy, -fy, 0.f}, {sz, wz, -fz, 0.f}, {-es, -eu, ef, 1.f}};
+    float m[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t0 = cp.m[0 + r] * view[k][0], t1 = cp.m[4 + r] * view[k][1];
+            const float t2 = cp.m[8 + r] * view[k][2], t3 = cp.m[12 + r] * view[k][3];
+            m[4 * k + r] = ((t0 + t1) + t2) + t3;
+        }
+    float4 *o = out + (size_t)l * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+}
+
+hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,
+                          hipStream_t s)
+{
+    Mat4Arg cp;
+    for (int i = 0; i < 16; ++i) cp.m[i] = cp16[i];
+    hipLaunchKernelGGL(cameras_kernel, dim3(ceil_div_u(count, kBlock)), dim3(kBlock), 0, s, count, eyes, dirs, up3[0], up3[1], up3[2],
+                       cp, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Random-walk controller, update_instance_random main.rs:381-402: in place, O(N).
+// The jitter stream is build-owned and counter based (seed, step, body): see the oracle's random_jitter.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float random_jitter(uint64_t seed, uint64_t step, uint32_t body, uint32_t which)
+{
+    uint64_t s = seed ^ (step * 0xD1B54A32D192ED03ull) ^ ((uint64_t)body * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)which << 62);
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(uint32_t)(z >> 40) * 0x1.0p-24f;
+    const float lo = -0.0001f, hi = 0.0001f;
+    const float scale = hi - lo;
+    const float v = scale * u;
+    return lo + v;
+}
+
+__global__ __launch_bounds__(kBlock) void random_step_kernel(uint32_t first, uint32_t count, float4 *__restrict__ pos,
+                                                             float4 *__restrict__ vel, uint64_t seed, uint64_t step)
+{
+    const uint32_t l = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (l >= count) return;
+    float4 p = pos[l], v = vel[l];
+    const float jx = random_jitter(seed, step, first + l, 0), jy = random_jitter(seed, step, first + l, 1);
+    v.x = v.x + jx;  // main.rs:392-396
+    v.y = v.y + jy;
+    v.z = v.z + 0.0f;
+    p.x = p.x + v.x;  // main.rs:397
+    p.y = p.y + v.y;
+    p.z = p.z + v.z;
+    pos[l] = p;
+    vel[l] = v;
+}
+
+hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *vel, uint64_t seed, uint64_t step, hipStream_t s)
+{
+    hipLaunchKernelGGL(random_step_kernel, dim3(ceil_div_u(count, kBlock)), dim3(kBlock), 0, s, first, count, pos, vel, seed, step);
+    return hipGetLastError();
+}
+
 // stride-3 host layout <-> 16-byte device records
 __global__ __launch_bounds__(kBlock) void pack_kernel(uint32_t count, const float *__restrict__ xyz, float4 *__restrict__ rec)
 {

@@ -102,6 +102,28 @@ class Scene:
         """k boids updates, device-resident and asynchronous; host mirrors are NOT refreshed."""
         check(self._lib.nb_step_boids(self._ctx, int(k), ctypes.byref(params) if params is not None else None), self._ctx)
 
+    def step_random(self, seed: int = 0, k: int = 1) -> None:
+        """k random-walk updates (update_instance_random, src/main.rs:381-402), then refresh the host mirrors."""
+        check(self._lib.nb_step_random(self._ctx, int(k), int(seed)), self._ctx)
+        self._refresh(True)
+
+    def cameras(self, up, cp) -> np.ndarray:
+        """CameraArray::update (src/gfx.rs:397-408) for the current state: per body cp * look_at_dir(position, velocity,
+        up).  ``cp`` is the array's constant correction*proj as a (4, 4) array whose [k] is column k.  Returns (n, 4, 4)."""
+        upv = np.ascontiguousarray(up, np.float32).reshape(3)
+        cpm = np.ascontiguousarray(cp, np.float32).reshape(16)
+        out = np.zeros((self.n, 4, 4), np.float32)
+        check(self._lib.nb_cameras(self._ctx, upv.ctypes.data, cpm.ctypes.data, out.ctypes.data), self._ctx)
+        return out
+
+    def device_state(self, with_instances: bool = True):
+        """Device pointers (ints) of the current position records, velocity records and model matrices: the zero-copy
+        hand-off.  Valid until the next step / upload / close."""
+        p, v, m = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check(self._lib.nb_device_state(self._ctx, ctypes.byref(p), ctypes.byref(v), ctypes.byref(m) if with_instances else None),
+              self._ctx)
+        return p.value, v.value, (m.value if with_instances else None)
+
     def sync(self) -> None:
         check(self._lib.nb_sync(self._ctx), self._ctx)
 

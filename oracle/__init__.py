@@ -53,6 +53,10 @@ def load() -> ctypes.CDLL:
         lib.nbo_run.restype = i
         lib.nbo_run_f64.argtypes = [vp, vp, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         lib.nbo_run_f64.restype = i
+        lib.nbo_cameras.argtypes = [vp, vp, vp, vp, vp, u32]
+        lib.nbo_cameras.restype = None
+        lib.nbo_random_step_range.argtypes = [vp, vp, vp, u32, u32, u64, u64]
+        lib.nbo_random_step_range.restype = None
         lib.nbo_boids_default_params.argtypes = [ctypes.POINTER(BoidsParams)]
         lib.nbo_boids_default_params.restype = None
         lib.nbo_boids_step_range.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, ctypes.POINTER(BoidsParams)]
@@ -146,4 +150,28 @@ def boids_step_range(old_pos, old_vel, first: int, count: int, params: BoidsPara
     inst = np.zeros((count, 4, 4), np.float32) if want_instances else None
     load().nbo_boids_step_range(op.ctypes.data, ov.ctypes.data, p.ctypes.data, v.ctypes.data,
                                 inst.ctypes.data if want_instances else None, len(op), first, count, ctypes.byref(bp))
+    return (p, v, inst) if want_instances else (p, v)
+
+
+def cameras(eyes, dirs, up, cp):
+    """CameraArray::update (gfx.rs:397-408): per entity (correction*proj) * look_at_dir(eye, dir, up); cp is the constant
+    correction*proj as a (4, 4) array whose [k] is column k."""
+    e = np.ascontiguousarray(eyes, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    u = np.ascontiguousarray(up, np.float32)
+    c = np.ascontiguousarray(cp, np.float32)
+    out = np.zeros((len(e), 4, 4), np.float32)
+    load().nbo_cameras(e.ctypes.data, d.ctypes.data, u.ctypes.data, c.ctypes.data, out.ctypes.data, len(e))
+    return out
+
+
+def random_run(pos, vel, k: int, seed: int, first_step: int = 0, want_instances: bool = False):
+    """k applications of update_instance_random (main.rs:381-402) with the build-owned counter-based stream."""
+    p = np.ascontiguousarray(pos, np.float32).copy()
+    v = np.ascontiguousarray(vel, np.float32).copy()
+    inst = np.zeros((len(p), 4, 4), np.float32) if want_instances else None
+    for s in range(k):
+        last = want_instances and s + 1 == k
+        load().nbo_random_step_range(p.ctypes.data, v.ctypes.data, inst.ctypes.data if last else None, 0, len(p), seed,
+                                     first_step + s)
     return (p, v, inst) if want_instances else (p, v)

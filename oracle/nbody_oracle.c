@@ -428,6 +428,88 @@ NBO_API int nbo_boids_run(float *pos3, float *vel3, float *inst16, uint32_t n, u
     return 0;
 }
 
+/* ====================================================================================
+ * CameraArray::update, src/gfx.rs:397-408 with build_camera src/gfx.rs:358-369:
+ * per entity  M = (OPENGL_TO_WGPU_MATRIX * perspective(fov, aspect, 1, 10000)) * look_at_dir(eye, dir, up).
+ * `correction * proj * view` associates to the left, so correction * proj is one constant matrix for the whole
+ * array: the caller passes it (16 floats, column-major) -- its tan() stays with the caller's cgmath::perspective.
+ * cgmath 0.17 semantics restated:
+ *   look_at_dir(eye, dir, up): f = dir.normalize(); s = f.cross(up).normalize(); u = s.cross(f);
+ *       columns (s.x, u.x, -f.x, 0), (s.y, u.y, -f.y, 0), (s.z, u.z, -f.z, 0), (-eye.dot(s), -eye.dot(u), eye.dot(f), 1)
+ *   normalize() = self * (1 / magnitude());  cross = (y*oz - z*oy, z*ox - x*oz, x*oy - y*ox);  dot = (xx + yy) + zz
+ *   Matrix4 * Matrix4 as in instance_matrix above.
+ * ==================================================================================== */
+static void normalize3(float v[3])
+{
+    const float mag = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const float s = 1.0f / mag;
+    v[0] = v[0] * s;
+    v[1] = v[1] * s;
+    v[2] = v[2] * s;
+}
+
+static void cross3(float out[3], const float a[3], const float b[3])
+{
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+NBO_API void nbo_cameras(const float *eye3, const float *dir3, const float *up3, const float *cp16, float *out16, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *eye = eye3 + 3 * (size_t)i;
+        float f[3] = {dir3[3 * (size_t)i], dir3[3 * (size_t)i + 1], dir3[3 * (size_t)i + 2]};
+        normalize3(f);
+        float s[3], u[3];
+        cross3(s, f, up3);
+        normalize3(s);
+        cross3(u, s, f);
+        const float view[4][4] = {{s[0], u[0], -f[0], 0.0f},
+                                  {s[1], u[1], -f[1], 0.0f},
+                                  {s[2], u[2], -f[2], 0.0f},
+                                  {-dot3(eye, s), -dot3(eye, u), dot3(eye, f), 1.0f}};
+        float *m = out16 + 16 * (size_t)i;
+        for (int k = 0; k < 4; ++k)      /* column k of cp * view */
+            for (int e = 0; e < 4; ++e) {
+                const float t0 = cp16[0 + e] * view[k][0], t1 = cp16[4 + e] * view[k][1];
+                const float t2 = cp16[8 + e] * view[k][2], t3 = cp16[12 + e] * view[k][3];
+                m[4 * k + e] = ((t0 + t1) + t2) + t3;
+            }
+    }
+}
+
+/* ====================================================================================
+ * Random-walk controller: update_instance_random, src/main.rs:381-402.
+ *   vel += (U[-0.0001, 0.0001), U[-0.0001, 0.0001), 0);  pos += vel;  matrix as above.
+ * The reference draws from the unseeded thread_rng of whichever rayon worker runs the body, so only the
+ * distribution can be kept; the stream here is build-owned and counter based: the two draws of body n at step t come
+ * from splitmix64 seeded with (seed, t, n), so any sharding and any execution order give the same bits.
+ * ==================================================================================== */
+static float random_jitter(uint64_t seed, uint64_t step, uint32_t body, uint32_t which)
+{
+    uint64_t s = seed ^ (step * 0xD1B54A32D192ED03ull) ^ ((uint64_t)body * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)which << 62);
+    return uniform_f32(&s, -0.0001f, 0.0001f);
+}
+
+NBO_API void nbo_random_step_range(float *pos3, float *vel3, float *inst16, uint32_t first, uint32_t count, uint64_t seed,
+                                   uint64_t step)
+{
+    for (uint32_t l = 0; l < count; ++l) {
+        float *v = vel3 + 3 * (size_t)l, *p = pos3 + 3 * (size_t)l;
+        const float jx = random_jitter(seed, step, first + l, 0), jy = random_jitter(seed, step, first + l, 1);
+        v[0] = v[0] + jx; /* main.rs:392-396  *vel += Vector3::new(jx, jy, 0.0) */
+        v[1] = v[1] + jy;
+        v[2] = v[2] + 0.0f;
+        p[0] = p[0] + v[0]; /* main.rs:397  *pos += *vel */
+        p[1] = p[1] + v[1];
+        p[2] = p[2] + v[2];
+        if (inst16) instance_matrix(inst16 + 16 * (size_t)l, p, v); /* main.rs:398-400 */
+    }
+}
+
 /* ------------------------------------------------------------------------------------
  * binary64 variant of the same recurrence: NOT the reference's arithmetic -- it exists to
  * show the rounding-noise floor of the chaotic system (sixth finding).

@@ -1,0 +1,113 @@
+"""GPU tests of SURVEY.md section 8f rows 2-4: device-resident hand-off of positions / velocities / model matrices,
+CameraArray::update (src/gfx.rs:397-408) and the random-walk controller (src/main.rs:381-402)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def perspective_cp(fovy_deg=45.0, aspect=16 / 9, near=1.0, far=10000.0):
+    """OPENGL_TO_WGPU_MATRIX * cgmath::perspective(...) (gfx.rs:365-368), column-major, as the caller would hand it over."""
+    f = np.float32(1.0 / np.tan(np.deg2rad(fovy_deg) / 2))
+    proj = np.zeros((4, 4), np.float32)        # proj[k] = column k
+    proj[0, 0] = f / np.float32(aspect)
+    proj[1, 1] = f
+    proj[2, 2] = np.float32((far + near) / (near - far))
+    proj[2, 3] = -1
+    proj[3, 2] = np.float32(2 * far * near / (near - far))
+    corr = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0.5, 0], [0, 0, 0.5, 1]], np.float32)   # columns
+    cp = np.zeros((4, 4), np.float32)
+    for k in range(4):
+        for r in range(4):
+            cp[k, r] = sum(np.float32(corr[c, r]) * np.float32(proj[k, c]) for c in range(4))
+    return cp.astype(np.float32)
+
+
+def test_cameras_bit_exact(nb, oracle):
+    n = 3000
+    pos, vel = oracle.init_state(n, 11)
+    pos[:, 2] = np.linspace(-5, 5, n, dtype=np.float32)
+    vel[:, 2] = np.float32(0.01)
+    up = np.array([0, 0, 1], np.float32)          # the eye cameras' shared normal
+    cp = perspective_cp()
+    with nb.Scene(pos, vel) as sc:
+        got = sc.cameras(up, cp)
+        sc.step_n(2)
+        got2 = sc.cameras(up, cp)
+        p2, v2 = sc.state()
+    ref = oracle.cameras(pos, vel, up, cp)
+    assert (bits(got) == bits(ref)).all()
+    assert (bits(got2) == bits(oracle.cameras(p2, v2, up, cp))).all()
+    # sanity: with cp = identity the matrix is look_at_dir: orthonormal rotation part
+    with nb.Scene(pos, vel) as sc:
+        view = sc.cameras(up, np.eye(4, dtype=np.float32))
+    rot = view[:, :3, :3]
+    assert np.allclose(np.einsum("nij,nkj->nik", rot, rot), np.eye(3), atol=1e-5)
+
+
+def test_cameras_degenerate_directions_like_the_reference(nb, oracle):
+    """Zero velocity -> normalize divides by zero; direction parallel to up -> zero cross product: NaNs in the same places."""
+    pos = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]], np.float32)
+    vel = np.array([[0, 0, 0], [0, 0, 2], [1, 0, 0]], np.float32)
+    up = np.array([0, 0, 1], np.float32)
+    with nb.Scene(pos, vel) as sc:
+        got = sc.cameras(up, np.eye(4, dtype=np.float32))
+    ref = oracle.cameras(pos, vel, up, np.eye(4, dtype=np.float32))
+    assert (np.isnan(got) == np.isnan(ref)).all()
+    ok = ~np.isnan(ref)
+    assert (bits(got)[ok] == bits(ref)[ok]).all()
+
+
+def test_random_controller_matches_oracle_stream(nb, oracle):
+    n = 5000
+    pos, vel = oracle.init_state(n, 3)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_random(seed=99, k=3)
+        p, v = sc._positions.copy(), sc._velocities.copy()
+        inst = sc._instances.copy()
+        sc.step_n(1)                 # n-body step in between: the step counter keeps running
+        sc.step_random(seed=99, k=2)
+        p2, v2 = sc._positions.copy(), sc._velocities.copy()
+    pr, vr, ir = oracle.random_run(pos, vel, 3, seed=99, want_instances=True)
+    assert (bits(p) == bits(pr)).all() and (bits(v) == bits(vr)).all()
+    assert np.allclose(inst, ir, rtol=0, atol=1e-6)
+    # distribution of the jitter (main.rs:393-394): U[-1e-4, 1e-4) per step on x and y, nothing on z
+    dv = (v - vel).astype(np.float64)
+    assert (dv[:, 2] == 0).all() and np.abs(dv[:, :2]).max() < 3e-4 and abs(dv[:, :2].mean()) < 5e-6
+    assert 0.8e-4 < dv[:, :2].std() < 1.2e-4          # sum of 3 uniforms of half-width 1e-4: sigma = 1e-4
+    pr2, vr2 = oracle.run(pr, vr, 1)
+    pr2, vr2 = oracle.random_run(pr2, vr2, 2, seed=99, first_step=4)
+    assert (bits(p2) == bits(pr2)).all() and (bits(v2) == bits(vr2)).all()
+
+
+def test_device_state_handoff(nb, oracle):
+    """Zero-copy hand-off: the device pointers the context hands out hold the current records and model matrices."""
+    import torch
+
+    n = 1000
+    pos, vel = oracle.init_state(n, 5)
+    hip = ctypes.CDLL(None)        # the one HIP runtime of this process
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(2)
+        p_dev, v_dev, m_dev = sc.device_state()
+        sc.sync()
+        assert p_dev and v_dev and m_dev
+        rec = np.zeros((n, 4), np.float32)
+        vrec = np.zeros((n, 4), np.float32)
+        mats = np.zeros((n, 4, 4), np.float32)
+        for dst, src in ((rec, p_dev), (vrec, v_dev), (mats, m_dev)):
+            assert hip.hipMemcpy(ctypes.c_void_p(dst.ctypes.data), ctypes.c_void_p(src), ctypes.c_size_t(dst.nbytes), 2) == 0
+        p, v = sc.state()
+        inst = sc.instances()
+    assert (bits(rec[:, :3]) == bits(p)).all() and (rec[:, 3] == 0).all()
+    assert (bits(vrec[:, :3]) == bits(v)).all()
+    assert (bits(mats) == bits(inst)).all()
+    p_ref, v_ref = oracle.run(pos, vel, 2)
+    assert (bits(p) == bits(p_ref)).all()
+    del torch
