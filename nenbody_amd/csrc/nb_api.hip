@@ -262,6 +262,28 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
     return NB_OK;
 }
 
+// Launch-API calls run on the device that owns the caller's buffers, not on whatever device happens to be current in
+// this thread (one process per GPU normally makes them equal; a host that forgot hipSetDevice would otherwise launch on
+// device 0 against another device's memory).
+int select_device_of(const void *dev_ptr, std::string *err)
+{
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, dev_ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return NB_OK;  // not a pointer the runtime knows (e.g. a test's fake address): leave the current device alone
+    }
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != attr.device) {
+        e = hipSetDevice(attr.device);
+        if (e != hipSuccess) {
+            *err = std::string("nb: hipSetDevice failed: ") + hipGetErrorString(e);
+            return NB_ERR_HIP;
+        }
+    }
+    return NB_OK;
+}
+
 uint64_t splitmix64(uint64_t &s)
 {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -655,6 +677,8 @@ NB_EXPORT int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t
     }
     rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
+    rc = select_device_of(pos_in, &g_tls_error);
+    if (rc != NB_OK) return rc;
     return launch_step_planned(p, pl, n_total, first, count, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
 }
 
@@ -675,6 +699,8 @@ NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_tot
     int rc = make_boids_args(p, n_total, first, count, &a, &tile, &g_tls_error);
     if (rc != NB_OK) return rc;
     rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    rc = select_device_of(pos_in, &g_tls_error);
     if (rc != NB_OK) return rc;
     a.pos_in = (const float4 *)pos_in;
     a.vel_in = (const float4 *)vel_in;
