@@ -138,3 +138,33 @@ def test_update_instance_nbody_argument_contract(nb):
     old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
     nb.update_instance_nbody(np.zeros((0, 4, 4), np.float32), pos, old_p, vel, old_v)
     assert (old_p == pos).all() and (old_v == vel).all()
+
+
+def test_context_calls_reject_a_null_context(nb):
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    assert lib.nb_step_boids(None, 1, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_step_random(None, 1, 0) == _lib.NB_ERR_INVALID
+    assert lib.nb_device_state(None, None, None, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_cameras(None, None, None, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_steps_done(None) == 0
+
+
+def test_boids_defaults_and_launch_validation(nb):
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    bp = nb.default_boids_params()
+    # src/main.rs:450-456
+    assert (bp.dt, bp.rule_1_distance, bp.rule_2_distance, bp.rule_3_distance) == (np.float32(0.04), 1000.0, 5.0, 500.0)
+    assert (bp.rule_1_scale, bp.rule_2_scale, bp.rule_3_scale) == (np.float32(0.02), np.float32(0.05), 0.5)
+    a, b, c, d = 0x1000, 0x2000, 0x3000, 0x4000   # never dereferenced: validation fails first
+    assert lib.nb_launch_boids_step(ctypes.byref(bp), 16, 0, 16, a, b, a, d, None) == _lib.NB_ERR_INVALID   # pos aliases
+    assert lib.nb_launch_boids_step(ctypes.byref(bp), 16, 0, 16, a, b, c, b, None) == _lib.NB_ERR_INVALID   # vel aliases
+    assert lib.nb_launch_boids_step(ctypes.byref(bp), 16, 8, 9, a, b, c, d, None) == _lib.NB_ERR_INVALID    # range
+    bp.tile = 100
+    assert lib.nb_launch_boids_step(ctypes.byref(bp), 16, 0, 16, a, b, c, d, None) == _lib.NB_ERR_INVALID
+    assert "tile" in _lib.last_error()
+    assert lib.nb_launch_cameras(0, a, b, c, d, a, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_random_step(0, 0, a, b, 1, 0, None) == _lib.NB_ERR_INVALID
