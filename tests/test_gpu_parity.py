@@ -313,6 +313,28 @@ def test_strict_full_size_sampled_bodies_vs_oracle_and_shard_invariance(nb, orac
     assert_bits_equal(v8, v)
 
 
+def test_config5_size_one_million_bodies_sampled(nb, oracle):
+    """BASELINE config 5 size, N = 1 048 576: one FAST and one STRICT step; sampled bodies folded over all j by the oracle."""
+    n = 1 << 20
+    pos, vel = nb.init_state(n, 1234)
+    idx = np.unique(np.concatenate([np.arange(0, 8), np.arange(n - 8, n), np.linspace(8, n - 9, 48).astype(np.int64)]))
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        p, v = sc.state()
+    with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+        sc.step_n(1)
+        pf, vf = sc.state()
+    acc = 0.0
+    for i in idx:
+        p_ref, v_ref = oracle.step_range(pos, vel[i:i + 1], int(i), 1)
+        assert (bits(p[i]) == bits(p_ref[0])).all() and (bits(v[i]) == bits(v_ref[0])).all(), f"STRICT body {i}"
+        acc = max(acc, float(np.abs(v_ref[0] - vel[i]).max()))
+        # a million-term binary32 sum: FAST's reassociated partial sums and the reference's sequential sum each carry
+        # ~1e-5 relative rounding error of their own, so the tolerance is 1e-4 of the step's velocity change here
+        assert np.abs(vf[i] - v_ref[0]).max() <= 1e-4 * float(np.abs(v_ref[0] - vel[i]).max()) + 1e-9, f"FAST body {i}"
+    assert acc > 0
+
+
 def test_fast_full_size_close_to_strict_and_shard_consistent(nb):
     n = 131072
     pos, vel = nb.init_state(n, 1234)

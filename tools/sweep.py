@@ -117,6 +117,12 @@ def main():
         return shard_sweep()
     if what == "lanes":
         return lanes_sweep()
+    if what == "configs":
+        # the BASELINE.json configurations on one GPU, library defaults
+        for n, steps in ((1024, 1000), (16384, 100), (131072, 20), (1048576, 2)):
+            for mode in (nb.NB_MODE_STRICT, nb.NB_MODE_FAST):
+                run(n, mode, steps, {})
+        return
     if what == "boids":
         for n in (16384, 131072):
             for tile in (256, 512, 1024):
