@@ -117,6 +117,12 @@ def main():
         return shard_sweep()
     if what == "lanes":
         return lanes_sweep()
+    if what == "strictone":
+        # STRICT at the sizes given on the command line (default 131072), shape from the environment
+        sizes = [int(x) for x in sys.argv[2:]] or [131072]
+        for n in sizes:
+            run(n, nb.NB_MODE_STRICT, max(2, min(10, int(2e11 / (float(n) * n)))), {})
+        return
     if what == "configs":
         # the BASELINE.json configurations on one GPU, library defaults
         for n, steps in ((1024, 1000), (16384, 100), (131072, 20), (1048576, 2)):
