@@ -148,6 +148,13 @@ int nb_sync(nb_ctx *ctx);
 /* Steps taken since nb_upload. */
 uint64_t nb_steps_done(const nb_ctx *ctx);
 
+/* Diagnostic: checks on the GPU that STRICT's shared-reciprocal division ladder equals the IEEE binary32 divide on
+ * `pairs` random (numerator, denominator) pairs drawn over the whole exponent rectangle the range guard admits for
+ * `params` (NULL = defaults), structured mantissas included.  *mismatches receives the number of differing results
+ * (expected 0); bad_pair, if non-NULL, receives one offending (n, d).  Returns NB_ERR_UNSUPPORTED when the parameters
+ * leave no guarded range (STRICT then always uses the IEEE divide). */
+int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair);
+
 /* -- launch API: caller-owned device memory ------------------------------------------------------------ *
  * For hosts that own the device buffers and the exchange step themselves (one process per GPU, RCCL
  * all-gather of positions between steps).  Device layout: one 16-byte record per body,

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "nb_cameras": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_cameras": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),

@@ -41,6 +41,7 @@ struct Plan {
     uint32_t slices;  // FAST: blockIdx.y slices of the j range
     uint32_t j_chunk;
     uint32_t lo_bits, hi_bits, force_ieee;  // STRICT guard
+    int guard_a, guard_b, guard_g, guard_c; // its exponents: coordinates in {0} U [2^a, 2^b], |G| in [2^g, 2^(g+1)), bias in [2^c, 2^(c+1))
     uint32_t force_3d;                      // 2 = never take the planar shortcut (NB_FORCE_3D=1: tests, measurements)
     uint32_t unroll;                        // STRICT: pairs in flight per lane (2, 4 or 8)
     uint32_t lanes;                         // STRICT: lanes per body (1 = plain; 2..16 = j-parallel, same summation order)
@@ -114,6 +115,10 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
             pl.lo_bits = (uint32_t)(a + 127) << 23;
             pl.hi_bits = (uint32_t)(b + 127) << 23;
             pl.force_ieee = 0;
+            pl.guard_a = a;
+            pl.guard_b = b;
+            pl.guard_g = g;
+            pl.guard_c = c;
         }
     }
     uint32_t f = 0;
@@ -633,6 +638,68 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (!pos_xyz && !vel_xyz && !inst_16n) NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NB_OK;
+}
+
+NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair)
+{
+    if (!mismatches) {
+        g_tls_error = "nb_selftest_divide: mismatches is null";
+        return NB_ERR_INVALID;
+    }
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    p.mode = NB_MODE_STRICT;
+    Plan pl;
+    int rc = make_plan(p, 1024, 1024, &pl, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    uint32_t forced = 0;
+    if (pl.force_ieee && !(env_u32("NB_STRICT_FORCE_IEEE", &forced) && forced)) {
+        g_tls_error = "nb_selftest_divide: these parameters have no guarded range (STRICT always divides with '/')";
+        return NB_ERR_UNSUPPORTED;
+    }
+    if (pl.force_ieee) {  // forced by the environment only: recompute the range without the override is not possible here
+        g_tls_error = "nb_selftest_divide: unset NB_STRICT_FORCE_IEEE";
+        return NB_ERR_UNSUPPORTED;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    // what the kernels can meet inside the guard (see make_plan):
+    //   d = |dp|^2 + bias  in [2^c, 2^max(2b+4, c+2)),   n = dx*G, nonzero dx in [2^(a-23), 2^(b+1)]  ->  |n| in [2^(a-23+g), 2^(b+g+2))
+    const int d_lo = pl.guard_c, d_hi = std::max(2 * pl.guard_b + 4, pl.guard_c + 2) - 1;
+    const int n_lo = pl.guard_a - 23 + pl.guard_g, n_hi = pl.guard_b + pl.guard_g + 1;
+    unsigned long long *d_bad = nullptr;
+    float *d_pair = nullptr;
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_pair, 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_pair, 0, 2 * sizeof(float));
+    const uint32_t blocks = 4096;
+    const uint64_t threads = (uint64_t)blocks * 256u;
+    uint64_t per_thread = (pairs + threads - 1) / threads;
+    if (per_thread > 0xffffffffull) per_thread = 0xffffffffull;
+    uint32_t control = 0;  // NB_SELFTEST_CONTROL=1: compare the UNCORRECTED product n*r instead (control arm: must report mismatches)
+    env_u32("NB_SELFTEST_CONTROL", &control);
+    if (e == hipSuccess)
+        e = nbk::launch_divide_selftest(blocks, seed, (uint32_t)per_thread, d_lo, d_hi, n_lo, n_hi, d_bad, d_pair, control != 0, nullptr);
+    unsigned long long bad = 0;
+    float pair[2] = {0.f, 0.f};
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pair, d_pair, sizeof(pair), hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (d_pair) (void)hipFree(d_pair);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_selftest_divide: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    *mismatches = bad;
+    if (bad_pair) {
+        bad_pair[0] = pair[0];
+        bad_pair[1] = pair[1];
+    }
     return NB_OK;
 }
 

@@ -42,6 +42,8 @@ hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel
 hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,
                           hipStream_t s);
 hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *vel, uint64_t seed, uint64_t step, hipStream_t s);
+hipError_t launch_divide_selftest(uint32_t blocks, uint64_t seed, uint32_t per_thread, int d_lo, int d_hi, int n_lo, int n_hi,
+                                  unsigned long long *mismatches, float *first_bad, bool single_correction, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 

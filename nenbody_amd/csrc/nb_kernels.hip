@@ -1000,6 +1000,70 @@ hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *ve
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Self-test of the STRICT division (diagnostic; nb_selftest_divide): random numerators and denominators covering the
+// whole exponent rectangle the range guard admits, the shared-reciprocal ladder against the IEEE '/'.
+// Every thread draws `per_thread` pairs: mantissas uniform (plus all-zeros / all-ones / one-bit patterns every 8th
+// draw), exponents uniform in [d_lo, d_hi] x [n_lo, n_hi], random numerator sign.  Mismatching bit patterns are counted.
+// ------------------------------------------------------------------------------------------------
+template <bool SINGLE_CORRECTION>  // true = control arm (no correction step at all)
+__global__ __launch_bounds__(kBlock) void divide_selftest_kernel(uint64_t seed, uint32_t per_thread, int d_lo, int d_hi, int n_lo,
+                                                                 int n_hi, unsigned long long *mismatches, float *first_bad)
+{
+    uint64_t s = seed ^ ((uint64_t)(blockIdx.x * (uint32_t)kBlock + threadIdx.x) * 0x9E3779B97F4A7C15ull);
+    auto next = [&]() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    unsigned long long bad = 0;
+    for (uint32_t i = 0; i < per_thread; ++i) {
+        const uint64_t a = next(), b = next();
+        uint32_t md = (uint32_t)(a & 0x7fffffu), mn = (uint32_t)(b & 0x7fffffu);
+        if ((i & 7u) == 7u) {  // structured mantissas: the reciprocal refinement's hard cases live at the ends
+            const uint32_t sel = (uint32_t)(a >> 23) & 3u;
+            md = sel == 0 ? 0u : sel == 1 ? 0x7fffffu : sel == 2 ? (1u << ((a >> 25) % 23)) : 0x7fffffu ^ (1u << ((a >> 25) % 23));
+            const uint32_t seln = (uint32_t)(b >> 23) & 3u;
+            mn = seln == 0 ? 0u : seln == 1 ? 0x7fffffu : mn;
+        }
+        const int ed = d_lo + (int)((a >> 32) % (uint64_t)(d_hi - d_lo + 1));
+        const int en = n_lo + (int)((b >> 32) % (uint64_t)(n_hi - n_lo + 1));
+        const float d = __uint_as_float(((uint32_t)(ed + 127) << 23) | md);
+        const float n = __uint_as_float(((uint32_t)(b >> 63) << 31) | ((uint32_t)(en + 127) << 23) | mn);
+        const float r0 = __builtin_amdgcn_rcpf(d);
+        const float e = __builtin_fmaf(-d, r0, 1.0f);
+        const float r = __builtin_fmaf(e, r0, r0);
+        float q_ladder;
+        if (SINGLE_CORRECTION) {  // control arm: the uncorrected product n * r, off by an ulp in a few percent of the draws
+            q_ladder = n * r;
+        } else {
+            q_ladder = div_ladder(n, d, r);
+        }
+        const float q_ieee = n / d;
+        if (__float_as_uint(q_ladder) != __float_as_uint(q_ieee)) {
+            if (bad == 0 && first_bad) {
+                first_bad[0] = n;
+                first_bad[1] = d;
+            }
+            ++bad;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_divide_selftest(uint32_t blocks, uint64_t seed, uint32_t per_thread, int d_lo, int d_hi, int n_lo, int n_hi,
+                                  unsigned long long *mismatches, float *first_bad, bool single_correction, hipStream_t s)
+{
+    if (single_correction)
+        hipLaunchKernelGGL(divide_selftest_kernel<true>, dim3(blocks), dim3(kBlock), 0, s, seed, per_thread, d_lo, d_hi, n_lo, n_hi,
+                           mismatches, first_bad);
+    else
+        hipLaunchKernelGGL(divide_selftest_kernel<false>, dim3(blocks), dim3(kBlock), 0, s, seed, per_thread, d_lo, d_hi, n_lo, n_hi,
+                           mismatches, first_bad);
+    return hipGetLastError();
+}
+
 // stride-3 host layout <-> 16-byte device records
 __global__ __launch_bounds__(kBlock) void pack_kernel(uint32_t count, const float *__restrict__ xyz, float4 *__restrict__ rec)
 {

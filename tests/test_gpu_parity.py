@@ -505,3 +505,45 @@ def test_multirank_on_one_gpu_strict_equals_oracle(tmp_path, nb, oracle, world, 
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert_bits_equal(got["pos"], p_ref, f"rank {r} positions")
         assert_bits_equal(got["vel"], v_ref, f"rank {r} velocities")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the STRICT division ladder itself, against the IEEE divide, over the whole guarded exponent rectangle
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("g_,bias", [(0.001, 1e-7), (0.5, 0.01), (-2.0, 3.0), (1e-6, 1e-12)])
+def test_strict_division_ladder_equals_ieee_divide(nb, g_, bias):
+    """2^37 (1.4e11) random (numerator, denominator) pairs per parameter set, structured mantissas included: the shared-reciprocal
+    ladder STRICT uses inside the range guard must reproduce the correctly rounded quotient every time."""
+    from nenbody_amd import _lib
+
+    p = nb.default_params()
+    p.G, p.bias = g_, bias
+    bad = ctypes.c_uint64(123)
+    pair = np.zeros(2, np.float32)
+    rc = _lib.load().nb_selftest_divide(ctypes.byref(p), 1 << 37, 2024, ctypes.byref(bad), pair.ctypes.data)
+    assert rc == 0, _lib.last_error()
+    assert bad.value == 0, f"{bad.value} mismatches, e.g. n={pair[0]!r} d={pair[1]!r}"
+
+
+def test_division_selftest_can_fail(nb, monkeypatch):
+    """Control arm: comparing the uncorrected product n * (1/d) with the IEEE quotient must report mismatches (a few
+    percent of the draws are one ulp off) -- i.e. the self-test is able to fail."""
+    from nenbody_amd import _lib
+
+    monkeypatch.setenv("NB_SELFTEST_CONTROL", "1")
+    bad = ctypes.c_uint64(0)
+    pair = np.zeros(2, np.float32)
+    pairs = 1 << 30
+    rc = _lib.load().nb_selftest_divide(None, pairs, 7, ctypes.byref(bad), pair.ctypes.data)
+    assert rc == 0, _lib.last_error()
+    assert 0.001 * pairs < bad.value < 0.6 * pairs
+    assert np.isfinite(np.float32(pair[0]) / np.float32(pair[1]))
+
+
+def test_selftest_refuses_parameters_without_a_guarded_range(nb):
+    from nenbody_amd import _lib
+
+    p = nb.default_params()
+    p.bias = 0.0            # no softening: d can be 0 -> STRICT always uses the IEEE divide
+    bad = ctypes.c_uint64(0)
+    assert _lib.load().nb_selftest_divide(ctypes.byref(p), 1024, 1, ctypes.byref(bad), None) == _lib.NB_ERR_UNSUPPORTED
