@@ -23,7 +23,14 @@ params = nb.default_params(mode=mode)
 v4 = torch.zeros((count, 4), device=dev)
 sb = be.scratch_bytes(params, n_total, count)
 scratch = torch.empty((sb,), dtype=torch.uint8, device=dev) if sb else None
-for _ in range(reps):
-    be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
+if os.environ.get("NB_MODE") == "boids":
+    vin = torch.zeros((n_total, 4)); vin[:, :3] = torch.from_numpy(vel); vin = vin.to(dev)
+    vout = torch.zeros_like(vin)
+    bp = nb.default_boids_params()
+    for _ in range(reps):
+        be.boids_step(bp, n_total, 0, count, cur, vin, nxt, vout)
+else:
+    for _ in range(reps):
+        be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
 torch.cuda.synchronize()
 print("done", count, reps)
