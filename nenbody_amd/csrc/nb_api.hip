@@ -136,7 +136,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (pl.lanes != 1 && pl.lanes != 2 && pl.lanes != 4 && pl.lanes != 8 && pl.lanes != 16) pl.lanes = 1;
     pl.unroll = pl.lanes == 1 ? 8 : (pl.lanes == 16 ? 2 : 4);
     env_u32("NB_STRICT_UNROLL", &pl.unroll);
-    if (pl.lanes == 1 && pl.unroll != 4 && pl.unroll != 8) pl.unroll = 8;
+    if (pl.lanes == 1 && pl.unroll != 4 && pl.unroll != 8 && pl.unroll != 16) pl.unroll = 8;
     if (pl.lanes > 1 && pl.unroll != 2 && pl.unroll != 4) pl.unroll = 4;
     if (pl.lanes == 16) pl.unroll = 2;
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 512) pl.tile = 1024;  // built j-parallel shapes: 256, 1024
@@ -238,7 +238,7 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
         *err = "nb: boids: need count > 0 and [first, first+count) inside n_total";
         return NB_ERR_INVALID;
     }
-    uint32_t t = p.tile ? p.tile : 256u;
+    uint32_t t = p.tile ? p.tile : 1024u;
     if (p.tile == 0) env_u32("NB_BOIDS_TILE", &t);
     if (!valid_tile(t)) {
         *err = "nb: boids params.tile must be 0, 256, 512 or 1024";

@@ -384,9 +384,9 @@ __device__ __forceinline__ void boids_fold_tile(BoidsAcc &s, const float4 *tp, c
                                                 const float4 pn, const float4 vn, float r1, float t2, float t3)
 {
     int j = 0;
-    for (; j + 4 <= nj; j += 4) {
+    for (; j + 16 <= nj; j += 16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 16; ++u)
             boids_pair<SELF, MASKED, PLANAR>(s, tp[j + u], tv[j + u], j0 + (uint32_t)(j + u), gn, pn, vn, r1, t2, t3);
     }
     for (; j < nj; ++j) boids_pair<SELF, MASKED, PLANAR>(s, tp[j], tv[j], j0 + (uint32_t)j, gn, pn, vn, r1, t2, t3);
@@ -1142,6 +1142,7 @@ hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint
     NBK_CASE(512, 8, 1);
     NBK_CASE(1024, 4, 1);
     NBK_CASE(1024, 8, 1);
+    NBK_CASE(1024, 16, 1);
     return hipErrorInvalidValue;
 }
 #endif
