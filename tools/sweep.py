@@ -113,6 +113,9 @@ def lanes_sweep(n_total=131072):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "strict"
+    known = {"strict", "strict2", "fast", "fast2", "shard", "lanes", "pc", "boids", "configs", "strictone"}
+    if what not in known:
+        raise SystemExit(f"unknown sweep {what!r}; one of {sorted(known)}")
     if what == "shard":
         return shard_sweep()
     if what == "lanes":
