@@ -1,0 +1,106 @@
+"""Randomised differential tests on the GPU: many small random problems (sizes, shard ranges, constants, data scales,
+launch shapes) -- STRICT n-body and boids against the oracle bit for bit, FAST against a tolerance.  Seeded, so a failure
+is reproducible from the printed case."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def random_state(rng, n):
+    scale = float(rng.choice([1e-3, 0.1, 1.0, 30.0, 1e3, 1e5]))
+    pos = (rng.uniform(-1, 1, (n, 3)) * scale).astype(np.float32)
+    vel = (rng.uniform(-1, 1, (n, 3)) * float(rng.choice([0.0, 1e-3, 0.1, 2.0]))).astype(np.float32)
+    kind = rng.integers(0, 4)
+    if kind == 0:        # planar, like the reference's initial state
+        pos[:, 2] = 0
+        vel[:, 2] = 0
+    elif kind == 1:      # clustered: many coincident and nearly coincident bodies
+        pos[rng.integers(0, n, n // 2)] = pos[rng.integers(0, n, n // 2)]
+    elif kind == 2 and n > 4:   # a few outliers far outside the STRICT ladder's range
+        pos[rng.integers(0, n, 3)] *= np.float32(1e9)
+        pos[rng.integers(0, n, 2)] *= np.float32(1e-30)
+    return pos, vel
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 257, 700, 1500, 2300]))
+    k = int(rng.integers(1, 4))
+    shape = rng.choice(["auto", "lanes1", "lanes2", "lanes4", "lanes8", "lanes16", "pc8", "pc14"])
+    if shape.startswith("pc"):
+        monkeypatch.setenv("NB_STRICT_PC", shape[2:])
+    elif shape.startswith("lanes"):
+        monkeypatch.setenv("NB_STRICT_PC", "0")
+        monkeypatch.setenv("NB_STRICT_LANES", shape[5:])
+    p = nb.default_params()
+    p.dt = float(rng.choice([0.1, 0.01, 1.0]))
+    p.G = float(rng.choice([0.001, 1.0, -0.05, 1e-6]))
+    p.bias = float(rng.choice([1e-7, 1e-3, 2.0]))
+    p.tile = int(rng.choice([0, 256, 1024]))
+    pos, vel = random_state(rng, n)
+    with nb.Scene(pos, vel, p) as sc:
+        sc.step_n(k)
+        got_p, got_v = sc.state()
+    ref_p, ref_v = oracle.run(pos, vel, k, np.float32(p.dt), np.float32(p.G), np.float32(p.bias))
+    what = f"case {case}: n={n} k={k} shape={shape} dt={p.dt} G={p.G} bias={p.bias} tile={p.tile}"
+    nan = np.isnan(ref_p)
+    assert (np.isnan(got_p) == nan).all(), what
+    assert (bits(got_p)[~nan] == bits(ref_p)[~nan]).all(), what
+    nanv = np.isnan(ref_v)
+    assert (bits(got_v)[~nanv] == bits(ref_v)[~nanv]).all(), what
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_boids_random_problems_bit_exact(nb, oracle, monkeypatch, case):
+    rng = np.random.default_rng(2000 + case)
+    n = int(rng.choice([1, 3, 64, 100, 256, 300, 900, 1300, 2100]))
+    k = int(rng.integers(1, 4))
+    monkeypatch.setenv("NB_BOIDS_FORCE", str(int(rng.integers(0, 4))))
+    bp, obp = nb.default_boids_params(tile=int(rng.choice([0, 256, 512]))), oracle.boids_params()
+    for name, choices in (("rule_1_distance", [1000.0, 50.0, 1e6]), ("rule_2_distance", [5.0, 0.5, 40.0]),
+                          ("rule_3_distance", [500.0, 0.3, 2.0]), ("dt", [0.04, 0.5]), ("rule_1_scale", [0.02, -0.01]),
+                          ("rule_2_scale", [0.05, 1.0]), ("rule_3_scale", [0.5, 0.0])):
+        val = float(rng.choice(choices))
+        setattr(bp, name, val)
+        setattr(obp, name, val)
+    pos, vel = random_state(rng, n)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_boids_n(k, bp)
+        got_p, got_v = sc.state()
+    ref_p, ref_v = oracle.boids_run(pos, vel, k, obp)
+    what = f"case {case}: n={n} k={k}"
+    nan = np.isnan(ref_p)
+    assert (np.isnan(got_p) == nan).all(), what
+    assert (bits(got_p)[~nan] == bits(ref_p)[~nan]).all(), what
+    nanv = np.isnan(ref_v)
+    assert (bits(got_v)[~nanv] == bits(ref_v)[~nanv]).all(), what
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
+    rng = np.random.default_rng(3000 + case)
+    n = int(rng.choice([64, 300, 1000, 2500, 4000]))
+    monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
+    monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
+    pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
+    vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
+    if case % 2 == 0:
+        pos[:, 2] = 0
+        vel[:, 2] = 0
+    with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+        sc.step_n(1)
+        got_p, got_v = sc.state()
+    ref_p, ref_v = oracle.run(pos, vel, 1)
+    acc = np.abs(ref_v - vel).max()
+    # relative force error per step, plus one ulp of the velocity itself (v + a*dt is rounded after the sum)
+    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n}"
+    assert np.abs(got_p - ref_p).max() <= 1e-5, f"case {case}"
