@@ -160,6 +160,42 @@ __device__ __forceinline__ void fold_tile_strict(const float4 *tile, int nj, int
                                                  float &sx, float &sy, float &sz)
 {
     int g = 0;
+    if (S == 1 && !IEEE) {
+        // One lane per body, ladder path: two groups of U pairs per trip with the record reads of each group issued a
+        // full group ahead (A is read while B is evaluated and vice versa, no register copies), so the ~130-cycle LDS
+        // latency is not exposed -- at N = 131 072 only two waves share a SIMD and nothing else would hide it.
+        // Same pairs, same order of additions.
+        auto eval = [&](const float4 (&rec)[U]) {
+            float qx[U], qy[U], qz[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pair_strict<IEEE, PLANAR>(rec[u], xi, yi, zi, G, qx[u], qy[u], qz[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // main.rs:430  sum + term, strictly in index order
+                sx = sx + qx[u];
+                sy = sy + qy[u];
+                if (!PLANAR) sz = sz + qz[u];
+            }
+        };
+        if (2 * U <= nj) {
+            float4 ra[U], rb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ra[u] = tile[u];
+            for (; g + 4 * U <= nj; g += 2 * U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) rb[u] = tile[g + U + u];
+                eval(ra);
+#pragma unroll
+                for (int u = 0; u < U; ++u) ra[u] = tile[g + 2 * U + u];
+                eval(rb);
+            }
+            // ra holds group g; one more group is guaranteed (g + 2U <= nj)
+#pragma unroll
+            for (int u = 0; u < U; ++u) rb[u] = tile[g + U + u];
+            eval(ra);
+            eval(rb);
+            g += 2 * U;
+        }
+    }
     for (; g + U * S <= nj; g += U * S) {
         float qx[U], qy[U], qz[U];
 #pragma unroll
