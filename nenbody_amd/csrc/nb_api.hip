@@ -231,6 +231,14 @@ float sqrt_threshold(float r)
     return x;
 }
 
+// boids launch shape: one lane per body from 65 536 bodies per rank, the producer/consumer form below (NB_BOIDS_PC overrides)
+uint32_t boids_use_pc(uint32_t count)
+{
+    uint32_t pc = count < 65536u ? 1u : 0u;
+    env_u32("NB_BOIDS_PC", &pc);
+    return pc;
+}
+
 int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,
                     uint32_t *tile, std::string *err)
 {
@@ -531,7 +539,7 @@ NB_EXPORT int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *para
         a.pos_out = ctx->pos[ctx->cur ^ 1];
         a.vel_in = ctx->vel;
         a.vel_out = ctx->vel_alt;
-        NB_HIP(ctx, nbk::launch_boids(a, tile, ctx->stream));
+        NB_HIP(ctx, nbk::launch_boids(a, tile, boids_use_pc(a.count), ctx->stream));
         ctx->cur ^= 1;
         std::swap(ctx->vel, ctx->vel_alt);
         ctx->steps++;
@@ -773,7 +781,7 @@ NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_tot
     a.vel_in = (const float4 *)vel_in;
     a.pos_out = (float4 *)pos_out;
     a.vel_out = (float4 *)vel_out;
-    hipError_t e = nbk::launch_boids(a, tile, (hipStream_t)stream);
+    hipError_t e = nbk::launch_boids(a, tile, boids_use_pc(a.count), (hipStream_t)stream);
     if (e != hipSuccess) {
         g_tls_error = std::string("nb: boids kernel launch failed: ") + hipGetErrorString(e);
         return NB_ERR_HIP;

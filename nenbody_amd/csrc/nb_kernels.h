@@ -32,7 +32,7 @@ struct BoidsArgs {
     float s1, s2, s3;      // rule scales, main.rs:454-456
     uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form (tests)
 };
-hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s);
+hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t pc, hipStream_t s);  // pc != 0: producer/consumer form (64 bodies x 16 waves)
 
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_NOSLP_TU

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "nb_kernels.h"
 
 namespace nbk {
@@ -324,6 +326,32 @@ __global__ __launch_bounds__(kBlock) void step_strict_kernel(StepArgs a)
     }
 }
 
+// The nk chunk steps of one tile: step k = work(k, k & 1), then a barrier; `publish` (tile staging) runs before the last
+// barrier.  Two steps per loop trip so the ring parity is a literal, and no per-step condition other than the trip
+// count: the chunk loop is otherwise bound by the CU's single scalar unit (~35 SALU ops and several branches per wave
+// per chunk doubled the step time when roles, paths and tails were decided inside it).
+template <class Work, class Publish>
+__device__ __forceinline__ void pc_steps(int nk, Work work, Publish publish)
+{
+    int k = 0;
+    for (; k + 2 < nk; k += 2) {  // k stays even; leaves one or two steps
+        work(k, 0);
+        __syncthreads();
+        work(k + 1, 1);
+        __syncthreads();
+    }
+    if (nk - k == 2) {
+        work(k, 0);
+        __syncthreads();
+        ++k;
+        work(k, 1);
+    } else {
+        work(k, 0);
+    }
+    publish();
+    __syncthreads();
+}
+
 #ifdef NBK_NOSLP_TU
 // ------------------------------------------------------------------------------------------------
 // Boids controller: update_instance_boids, main.rs:443-526.
@@ -533,8 +561,332 @@ __global__ __launch_bounds__(kBlock) void boids_step_kernel(BoidsArgs a)
     }
 }
 
-hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, hipStream_t s)
+// ------------------------------------------------------------------------------------------------
+// Boids, producer/consumer form ("bpc"), for shards too small to fill the chip with one lane per body.  Boids has
+// EIGHT serial chains per body (centre x/y, count, repel x/y, match x/y, vcount; three more in 3-D), so the consumer
+// side is one wave per chain.  A workgroup owns 64 bodies (lane = body) and runs 16 waves:
+//   waves 0..7   CONSUMERS, one running sum each (main.rs:476, 487, 499), folding the previous 32-j chunk in j order:
+//                sum = fma(mask_j, src_j, sum) with the 0/1 (or 0/-1) masks the producers left in the LDS ring and
+//                src_j read straight from the SoA tile (a broadcast), four j's per ds_read_b128 on both
+//   waves 8..15  PRODUCERS, 4 consecutive j's each per chunk: squared distances and the three radius tests
+//                (main.rs:474-475, 485-486, 497-498), written as masks m1, m2 (-1/0), m3 to ring[parity][plane][body][j]
+// Only masks cross the ring (3 planes, 54 KB), one barrier per chunk, tiles of 8 chunks staged as SoA planes
+// (px, py, pz, vx, vy, vz) one tile ahead by the producers.  Same arithmetic as boids_pair: same bits.
+// Per-tile forms as in boids_step_kernel: the self test only in the tile holding the workgroup's bodies, select-on-
+// result instead of the masked FMA when a record is not finite, z chains only when some z is non-zero.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBpcConsumers = 8;
+constexpr int kBpcProducers = 8;
+constexpr int kBpcThreads = (kBpcConsumers + kBpcProducers) * 64;
+constexpr int kBpcChunk = kBpcProducers * 4;  // 32
+constexpr int kBpcStride = kBpcChunk + 4;
+constexpr int kBpcTile = 256;
+constexpr int kBpcChunksPerTile = kBpcTile / kBpcChunk;  // 8
+
+struct BpcRing {
+    float m[3][64][kBpcStride];  // masks of rule 1, 2 (negated), 3: [plane][body][j within chunk]
+};
+struct BpcTile {
+    float c[6][kBpcTile];  // px, py, pz, vx, vy, vz
+};
+enum BpcSrc { kSrcPx = 0, kSrcPy = 1, kSrcPz = 2, kSrcVx = 3, kSrcVy = 4, kSrcVz = 5, kSrcDx = 6, kSrcDy = 7, kSrcDz = 8, kSrcOne = 9 };
+
+// the three masks of 4 consecutive j's for this lane's body
+template <bool SELF, bool PLANAR>
+__device__ __forceinline__ void bpc_produce(const BpcTile &t, int jt, uint32_t jglobal, uint32_t gn, const float4 pn, const float4 vn,
+                                            float r1, float t2, float t3, BpcRing &ring, int j0, int lane)
 {
+    const float4 px = *reinterpret_cast<const float4 *>(&t.c[kSrcPx][jt]), py = *reinterpret_cast<const float4 *>(&t.c[kSrcPy][jt]);
+    const float4 vx = *reinterpret_cast<const float4 *>(&t.c[kSrcVx][jt]), vy = *reinterpret_cast<const float4 *>(&t.c[kSrcVy][jt]);
+    float4 pz = make_float4(0.f, 0.f, 0.f, 0.f), vz = pz;
+    if (!PLANAR) {
+        pz = *reinterpret_cast<const float4 *>(&t.c[kSrcPz][jt]);
+        vz = *reinterpret_cast<const float4 *>(&t.c[kSrcVz][jt]);
+    }
+    const float pxs[4] = {px.x, px.y, px.z, px.w}, pys[4] = {py.x, py.y, py.z, py.w}, pzs[4] = {pz.x, pz.y, pz.z, pz.w};
+    const float vxs[4] = {vx.x, vx.y, vx.z, vx.w}, vys[4] = {vy.x, vy.y, vy.z, vy.w}, vzs[4] = {vz.x, vz.y, vz.z, vz.w};
+    float m1[4], m2[4], m3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ne = SELF ? (jglobal + (uint32_t)u != gn) : true;          // main.rs:475 n != i
+        const float dx = pxs[u] - pn.x, dy = pys[u] - pn.y;
+        float d2 = (dx * dx) + (dy * dy);
+        if (!PLANAR) {
+            const float dz = pzs[u] - pn.z;
+            d2 = d2 + (dz * dz);
+        }
+        const float ex = vxs[u] - vn.x, ey = vys[u] - vn.y;
+        float e2 = (ex * ex) + (ey * ey);
+        if (!PLANAR) {
+            const float ez = vzs[u] - vn.z;
+            e2 = e2 + (ez * ez);
+        }
+        m1[u] = ((d2 < r1) && ne) ? 1.f : 0.f;    // main.rs:474-475
+        m2[u] = ((d2 <= t2) && ne) ? -1.f : 0.f;  // main.rs:485-486 (negated: repel SUBTRACTS)
+        m3[u] = ((e2 <= t3) && ne) ? 1.f : 0.f;   // main.rs:497-498
+    }
+    *reinterpret_cast<float4 *>(&ring.m[0][lane][j0]) = make_float4(m1[0], m1[1], m1[2], m1[3]);
+    *reinterpret_cast<float4 *>(&ring.m[1][lane][j0]) = make_float4(m2[0], m2[1], m2[2], m2[3]);
+    *reinterpret_cast<float4 *>(&ring.m[2][lane][j0]) = make_float4(m3[0], m3[1], m3[2], m3[3]);
+}
+
+// One chain over one chunk: sum = sum (+) mask_j * src_j for j = 0..nvalid-1 in order.  MASKED: fma form (finite data);
+// else select-on-result.  src: a tile plane, a difference to the own coordinate (repel), or the constant 1 (counts).
+template <int SRC, bool MASKED>
+__device__ __forceinline__ void bpc_chain(const float (*mrow)[kBpcStride], const BpcTile &t, int jt, float own, int lane, int nvalid,
+                                          float &sum)
+{
+    constexpr int plane = SRC == kSrcOne ? 0 : SRC >= kSrcDx ? SRC - kSrcDx : SRC;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        float4 mk[4], sv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mk[g] = *reinterpret_cast<const float4 *>(&mrow[lane][16 * h + 4 * g]);
+            sv[g] = SRC != kSrcOne ? *reinterpret_cast<const float4 *>(&t.c[plane][jt + 16 * h + 4 * g]) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float ms[4] = {mk[g].x, mk[g].y, mk[g].z, mk[g].w};
+            const float ss[4] = {sv[g].x, sv[g].y, sv[g].z, sv[g].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (16 * h + 4 * g + u >= nvalid) continue;  // uniform; only the last chunk of the set is short
+                float x = SRC == kSrcOne ? 1.f : ss[u];
+                if (SRC >= kSrcDx && SRC <= kSrcDz) x = x - own;  // p_i - p_n
+                if (MASKED) {
+                    sum = SRC == kSrcOne ? sum + ms[u] : __builtin_fmaf(ms[u], x, sum);
+                } else {  // select on the result: a skipped term leaves the sum untouched whatever x is
+                    const float cand = (SRC >= kSrcDx && SRC <= kSrcDz) ? sum - x : sum + x;
+                    sum = (ms[u] != 0.f) ? cand : sum;
+                }
+            }
+        }
+    }
+}
+
+// the chain(s) of consumer wave ROLE: sum_a always, sum_b a z chain in 3-D for roles 2, 3, 7
+template <int ROLE, bool MASKED, bool PLANAR>
+__device__ __forceinline__ void bpc_fold(const BpcRing &rg, const BpcTile &tl, int jt, const float4 pn, int lane, int nvalid, float &sum_a,
+                                         float &sum_b)
+{
+    if (ROLE == 0) bpc_chain<kSrcPx, MASKED>(rg.m[0], tl, jt, 0.f, lane, nvalid, sum_a);                     // centre x
+    if (ROLE == 1) bpc_chain<kSrcPy, MASKED>(rg.m[0], tl, jt, 0.f, lane, nvalid, sum_a);                     // centre y
+    if (ROLE == 2) {
+        bpc_chain<kSrcOne, MASKED>(rg.m[0], tl, jt, 0.f, lane, nvalid, sum_a);                               // count
+        if (!PLANAR) bpc_chain<kSrcPz, MASKED>(rg.m[0], tl, jt, 0.f, lane, nvalid, sum_b);                   // centre z
+    }
+    if (ROLE == 3) {
+        bpc_chain<kSrcDx, MASKED>(rg.m[1], tl, jt, pn.x, lane, nvalid, sum_a);                               // repel x
+        if (!PLANAR) bpc_chain<kSrcDz, MASKED>(rg.m[1], tl, jt, pn.z, lane, nvalid, sum_b);                  // repel z
+    }
+    if (ROLE == 4) bpc_chain<kSrcDy, MASKED>(rg.m[1], tl, jt, pn.y, lane, nvalid, sum_a);                    // repel y
+    if (ROLE == 5) bpc_chain<kSrcVx, MASKED>(rg.m[2], tl, jt, 0.f, lane, nvalid, sum_a);                     // match x
+    if (ROLE == 6) bpc_chain<kSrcVy, MASKED>(rg.m[2], tl, jt, 0.f, lane, nvalid, sum_a);                     // match y
+    if (ROLE == 7) {
+        bpc_chain<kSrcOne, MASKED>(rg.m[2], tl, jt, 0.f, lane, nvalid, sum_a);                               // vcount
+        if (!PLANAR) bpc_chain<kSrcVz, MASKED>(rg.m[2], tl, jt, 0.f, lane, nvalid, sum_b);                   // match z
+    }
+}
+
+// form (masked FMA / select, planar / 3-D) chosen once per call, outside the chunk loop
+template <int ROLE>
+__device__ __forceinline__ void bpc_fold_flags(uint32_t flags, const BpcRing &rg, const BpcTile &tl, int jt, const float4 pn, int lane,
+                                               int nvalid, float &sum_a, float &sum_b)
+{
+    const bool masked = (flags & kBoidsNonFinite) == 0u, planar = (flags & kBoidsNonPlanar) == 0u;
+    if (masked && planar)
+        bpc_fold<ROLE, true, true>(rg, tl, jt, pn, lane, nvalid, sum_a, sum_b);
+    else if (masked)
+        bpc_fold<ROLE, true, false>(rg, tl, jt, pn, lane, nvalid, sum_a, sum_b);
+    else
+        bpc_fold<ROLE, false, false>(rg, tl, jt, pn, lane, nvalid, sum_a, sum_b);
+}
+
+__global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
+{
+    __shared__ __attribute__((aligned(16))) BpcTile tile[2];
+    __shared__ __attribute__((aligned(16))) BpcRing ring[2];
+    __shared__ uint32_t tile_flags[2][8];
+    __shared__ float sums[11][64];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const uint32_t l = blockIdx.x * 64u + (uint32_t)lane;
+    const bool live = l < a.count;
+    const uint32_t gn = a.first + (live ? l : a.count - 1u);
+    const float4 pn = a.pos_in[gn];
+    const float4 vn = a.vel_in[gn];
+    auto wave_flags = [](uint32_t f) {
+        return (__any((int)(f & kBoidsNonFinite)) ? kBoidsNonFinite : 0u) | (__any((int)(f & kBoidsNonPlanar)) ? kBoidsNonPlanar : 0u);
+    };
+    const uint32_t self = wave_flags(boids_flags(pn, vn) | a.force_flags);  // same 64 bodies in every wave
+    const uint32_t own_lo = a.first + blockIdx.x * 64u, own_hi = own_lo + 64u;
+
+    const uint32_t n = a.n_total;
+    const uint32_t ntiles = (n + (uint32_t)kBpcTile - 1u) / (uint32_t)kBpcTile;
+    // loaders: producer waves 8..11 stage positions, 12..15 velocities (one record per thread)
+    const int ltid = tid - kBpcConsumers * 64;
+    const bool loads_pos = ltid >= 0 && ltid < kBpcTile, loads_vel = ltid >= kBpcTile && ltid < 2 * kBpcTile;
+    auto fetch = [&](uint32_t t) -> float4 {
+        const uint32_t j = t * (uint32_t)kBpcTile + (uint32_t)(ltid & (kBpcTile - 1));
+        if (loads_pos && j < n) return a.pos_in[j];
+        if (loads_vel && j < n) return a.vel_in[j];
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto publish = [&](int buf, float4 rec) {
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));  // keep the flag arithmetic at the use point
+        if (loads_pos || loads_vel) {
+            const int k = ltid & (kBpcTile - 1), base = loads_pos ? 0 : 3;
+            tile[buf].c[base + 0][k] = rec.x;
+            tile[buf].c[base + 1][k] = rec.y;
+            tile[buf].c[base + 2][k] = rec.z;
+            auto nonfinite = [](float c) { return (__float_as_uint(c) & 0x7f800000u) == 0x7f800000u ? kBoidsNonFinite : 0u; };
+            uint32_t f = nonfinite(rec.x) | nonfinite(rec.y) | nonfinite(rec.z) |
+                         ((__float_as_uint(rec.z) & 0x7fffffffu) != 0u ? kBoidsNonPlanar : 0u);
+            f = wave_flags(f);
+            if (lane == 0) tile_flags[buf][wave - kBpcConsumers] = f;
+        }
+    };
+    publish(0, fetch(0u));
+    __syncthreads();
+
+    // per-tile bookkeeping shared by both roles (all wave-uniform)
+    struct TileInfo {
+        int tb, nk;
+        bool stage, has_self;
+        uint32_t flags, j_first;
+    };
+    auto tile_info = [&](uint32_t t) {
+        TileInfo ti;
+        ti.tb = (int)(t & 1u);
+        ti.stage = t + 1u < ntiles;
+        uint32_t f = self;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) f |= tile_flags[ti.tb][w];
+        ti.flags = __builtin_amdgcn_readfirstlane(f);
+        ti.j_first = t * (uint32_t)kBpcTile;
+        const uint32_t left = n - ti.j_first;
+        ti.nk = left >= (uint32_t)kBpcTile ? kBpcChunksPerTile : (int)((left + (uint32_t)kBpcChunk - 1u) / (uint32_t)kBpcChunk);
+        const uint32_t tile_n = left < (uint32_t)kBpcTile ? left : (uint32_t)kBpcTile;
+        ti.has_self = ti.j_first < own_hi && ti.j_first + tile_n > own_lo;
+        return ti;
+    };
+
+    // ---- consumer waves: the whole step for one role, forms chosen per tile ------------------------------
+    auto consumer = [&](auto role_tag) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        float sum_a = 0.f, sum_b = 0.f;
+        uint32_t prev_flags = 0u;
+        int last_nk = 1;
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const TileInfo ti = tile_info(t);
+            last_nk = ti.nk;
+            const bool first_tile = t == 0u;
+            auto nothing = [] {};
+            // at step k fold chunk k-1; step 0: the previous tile's last chunk (tile buffer tb^1, ring parity 1)
+            pc_steps(ti.nk, [&](int k, int par) {
+                if (k == 0) {
+                    if (!first_tile)
+                        bpc_fold_flags<ROLE>(prev_flags, ring[par ^ 1], tile[ti.tb ^ 1], (kBpcChunksPerTile - 1) * kBpcChunk, pn, lane,
+                                             kBpcChunk, sum_a, sum_b);
+                } else {
+                    bpc_fold_flags<ROLE>(ti.flags, ring[par ^ 1], tile[ti.tb], (k - 1) * kBpcChunk, pn, lane, kBpcChunk, sum_a, sum_b);
+                }
+            }, nothing);
+            prev_flags = ti.flags;
+        }
+        // drain: the last chunk of the step (its tile buffer and ring slot are still intact)
+        const int tb = (int)((ntiles - 1u) & 1u), k = last_nk - 1;
+        const uint32_t first_j = (ntiles - 1u) * (uint32_t)kBpcTile + (uint32_t)k * (uint32_t)kBpcChunk;
+        bpc_fold_flags<ROLE>(prev_flags, ring[k & 1], tile[tb], k * kBpcChunk, pn, lane, (int)(n - first_j), sum_a, sum_b);
+        sums[ROLE][lane] = sum_a;
+        if (ROLE == 2) sums[8][lane] = sum_b;   // centre z
+        if (ROLE == 3) sums[9][lane] = sum_b;   // repel z
+        if (ROLE == 7) sums[10][lane] = sum_b;  // match z
+    };
+
+    // ---- producer waves ------------------------------------------------------------------------------------
+    auto producer = [&]() {
+        const int j0 = (wave - kBpcConsumers) * 4;
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const TileInfo ti = tile_info(t);
+            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ti.stage) rec = fetch(t + 1u);  // in flight across the chunks of this tile
+            auto stage_next = [&]() {
+                if (ti.stage) publish(ti.tb ^ 1, rec);  // tile t+1 goes to the buffer tile t-1 used
+            };
+            const bool planar = (ti.flags & kBoidsNonPlanar) == 0u;
+            auto run = [&](auto self_tag, auto planar_tag) {
+                pc_steps(ti.nk, [&](int k, int par) {
+                    const int jt = k * kBpcChunk + j0;
+                    bpc_produce<decltype(self_tag)::value, decltype(planar_tag)::value>(tile[ti.tb], jt, ti.j_first + (uint32_t)jt, gn, pn,
+                                                                                        vn, a.r1, a.t2, a.t3, ring[par], j0, lane);
+                }, stage_next);
+            };
+            using T = std::true_type;
+            using F = std::false_type;
+            if (ti.has_self) {
+                if (planar) run(T{}, T{}); else run(T{}, F{});
+            } else {
+                if (planar) run(F{}, T{}); else run(F{}, F{});
+            }
+        }
+    };
+
+    switch (wave) {
+        case 0: consumer(std::integral_constant<int, 0>{}); break;
+        case 1: consumer(std::integral_constant<int, 1>{}); break;
+        case 2: consumer(std::integral_constant<int, 2>{}); break;
+        case 3: consumer(std::integral_constant<int, 3>{}); break;
+        case 4: consumer(std::integral_constant<int, 4>{}); break;
+        case 5: consumer(std::integral_constant<int, 5>{}); break;
+        case 6: consumer(std::integral_constant<int, 6>{}); break;
+        case 7: consumer(std::integral_constant<int, 7>{}); break;
+        default: producer(); break;
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+        float cx = sums[0][lane], cy = sums[1][lane], cz = sums[8][lane], mx = sums[5][lane], my = sums[6][lane], mz = sums[10][lane];
+        const float cnt = sums[2][lane], vcnt = sums[7][lane], rx = sums[3][lane], ry = sums[4][lane], rz = sums[9][lane];
+        if (cnt > 0.f) {  // main.rs:506-508
+            cx = cx / cnt;
+            cy = cy / cnt;
+            cz = cz / cnt;
+        }
+        if (vcnt > 0.f) {  // main.rs:510-512
+            mx = mx / vcnt;
+            my = my / vcnt;
+            mz = mz / vcnt;
+        }
+        const float ax = cx * a.s1, ay = cy * a.s1, az = cz * a.s1;  // main.rs:514
+        const float bx = rx * a.s2, by = ry * a.s2, bz = rz * a.s2;
+        const float gx = mx * a.s3, gy = my * a.s3, gz = mz * a.s3;
+        float vx = (ax + bx) + gx, vy = (ay + by) + gy, vz = (az + bz) + gz;
+        const float q0 = vx * vx, q1 = vy * vy, q2 = vz * vz;
+        const float mag = __builtin_sqrtf((q0 + q1) + q2);  // main.rs:516-518
+        if (mag > 1.0f) {
+            const float sc = 1.0f / mag;
+            vx = vx * sc;
+            vy = vy * sc;
+            vz = vz * sc;
+        }
+        const float sx = vx * a.dt, sy = vy * a.dt, sz = vz * a.dt;  // main.rs:521
+        a.vel_out[a.first + l] = make_float4(vx, vy, vz, 0.f);
+        a.pos_out[a.first + l] = make_float4(sx + pn.x, sy + pn.y, sz + pn.z, 0.f);
+    }
+}
+
+hipError_t launch_boids_pc(const BoidsArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(boids_pc_kernel, dim3(ceil_div_u(a.count, 64)), dim3(kBpcThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t pc, hipStream_t s)
+{
+    if (pc) return launch_boids_pc(a, s);
     const dim3 grid(ceil_div_u(a.count, kBlock)), block(kBlock);
     switch (tile) {
         case 256: hipLaunchKernelGGL(boids_step_kernel<256>, grid, block, 0, s, a); break;
@@ -629,32 +981,6 @@ __device__ __forceinline__ void pc_consume(const float (*row)[PcShape<NP>::kStri
             }
         }
     }
-}
-
-// The nk chunk steps of one tile: step k = work(k, k & 1), then a barrier; `publish` (tile staging) runs before the last
-// barrier.  Two steps per loop trip so the ring parity is a literal, and no per-step condition other than the trip
-// count: the chunk loop is otherwise bound by the CU's single scalar unit (~35 SALU ops and several branches per wave
-// per chunk doubled the step time when roles, paths and tails were decided inside it).
-template <class Work, class Publish>
-__device__ __forceinline__ void pc_steps(int nk, Work work, Publish publish)
-{
-    int k = 0;
-    for (; k + 2 < nk; k += 2) {  // k stays even; leaves one or two steps
-        work(k, 0);
-        __syncthreads();
-        work(k + 1, 1);
-        __syncthreads();
-    }
-    if (nk - k == 2) {
-        work(k, 0);
-        __syncthreads();
-        ++k;
-        work(k, 1);
-    } else {
-        work(k, 0);
-    }
-    publish();
-    __syncthreads();
 }
 
 template <int NP>

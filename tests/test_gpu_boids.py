@@ -26,11 +26,13 @@ def cloud(oracle, n, seed, scale=0.3):
     return (pos * np.float32(scale)).astype(np.float32), vel
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "select", "masked3d", "select3d"])
+@pytest.fixture(params=[(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 1), (3, 1)],
+                ids=["auto", "select", "masked3d", "select3d", "pc-auto", "pc-select", "pc-masked3d", "pc-select3d"])
 def force(request, monkeypatch):
-    """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form.
-    Every arithmetic form must give the same bits."""
-    monkeypatch.setenv("NB_BOIDS_FORCE", str(request.param))
+    """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form;
+    NB_BOIDS_PC: one lane per body (0) or the producer/consumer form (1).  Every form must give the same bits."""
+    monkeypatch.setenv("NB_BOIDS_FORCE", str(request.param[0]))
+    monkeypatch.setenv("NB_BOIDS_PC", str(request.param[1]))
     return request.param
 
 

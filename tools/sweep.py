@@ -113,7 +113,7 @@ def lanes_sweep(n_total=131072):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "strict"
-    known = {"strict", "strict2", "fast", "fast2", "shard", "lanes", "pc", "boids", "configs", "strictone"}
+    known = {"strict", "strict2", "fast", "fast2", "shard", "lanes", "pc", "boids", "boidsshard", "configs", "strictone"}
     if what not in known:
         raise SystemExit(f"unknown sweep {what!r}; one of {sorted(known)}")
     if what == "shard":
@@ -125,6 +125,41 @@ def main():
         sizes = [int(x) for x in sys.argv[2:]] or [131072]
         for n in sizes:
             run(n, nb.NB_MODE_STRICT, max(2, min(10, int(2e11 / (float(n) * n)))), {})
+        return
+    if what == "boidsshard":
+        import torch
+
+        from nenbody_amd.dist import HipBackend
+
+        be = HipBackend()
+        dev = torch.device("cuda", 0)
+        n_total = 131072
+        pos, vel = nb.init_state(n_total, 1234)
+
+        def rec(a):
+            t = torch.zeros((n_total, 4))
+            t[:, :3] = torch.from_numpy(a)
+            return t.to(dev)
+
+        pin, vin = rec(pos), rec(vel)
+        pout, vout = torch.zeros_like(pin), torch.zeros_like(vin)
+        bp = nb.default_boids_params()
+        for f3d in (0, 2):
+            for world in (1, 2, 4, 8):
+                count = n_total // world
+                for pc in (0, 1):
+                    os.environ["NB_BOIDS_PC"] = str(pc)
+                    os.environ["NB_BOIDS_FORCE"] = str(f3d)
+                    for _ in range(2):
+                        be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
+                    torch.cuda.synchronize()
+                    reps = 3
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / reps
+                    print(f"boids force={f3d} world={world} count={count:7d} pc={pc} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
         return
     if what == "configs":
         # the BASELINE.json configurations on one GPU, library defaults
