@@ -231,10 +231,11 @@ float sqrt_threshold(float r)
     return x;
 }
 
-// boids launch shape: one lane per body from 65 536 bodies per rank, the producer/consumer form below (NB_BOIDS_PC overrides)
+// boids launch shape: the producer/consumer form below 80 K bodies per rank, one lane per body above (NB_BOIDS_PC overrides).
+// Measured at N = 131 072 (tools/sweep.py boidsshard): 65 536 bodies 6.68 ms against 7.82; 131 072: 13.4 against 8.5.
 uint32_t boids_use_pc(uint32_t count)
 {
-    uint32_t pc = count < 65536u ? 1u : 0u;
+    uint32_t pc = count < 81920u ? 1u : 0u;
     env_u32("NB_BOIDS_PC", &pc);
     return pc;
 }

@@ -565,49 +565,64 @@ __global__ __launch_bounds__(kBlock) void boids_step_kernel(BoidsArgs a)
 // Boids, producer/consumer form ("bpc"), for shards too small to fill the chip with one lane per body.  Boids has
 // EIGHT serial chains per body (centre x/y, count, repel x/y, match x/y, vcount; three more in 3-D), so the consumer
 // side is one wave per chain.  A workgroup owns 64 bodies (lane = body) and runs 16 waves:
-//   waves 0..7   CONSUMERS, one running sum each (main.rs:476, 487, 499), folding the previous 32-j chunk in j order:
+//   waves 0..7   CONSUMERS, one running sum each (main.rs:476, 487, 499), folding the previous 64-j chunk in j order:
 //                sum = fma(mask_j, src_j, sum) with the 0/1 (or 0/-1) masks the producers left in the LDS ring and
 //                src_j read straight from the SoA tile (a broadcast), four j's per ds_read_b128 on both
-//   waves 8..15  PRODUCERS, 4 consecutive j's each per chunk: squared distances and the three radius tests
+//   waves 8..15  PRODUCERS, 8 consecutive j's each per chunk: squared distances and the three radius tests
 //                (main.rs:474-475, 485-486, 497-498), written as masks m1, m2 (-1/0), m3 to ring[parity][plane][body][j]
 // Only masks cross the ring (3 planes, 54 KB), one barrier per chunk, tiles of 8 chunks staged as SoA planes
 // (px, py, pz, vx, vy, vz) one tile ahead by the producers.  Same arithmetic as boids_pair: same bits.
+// (Chunks are 64 j's, 8 per producer: the masks travel as binary16, see BpcRing.)
 // Per-tile forms as in boids_step_kernel: the self test only in the tile holding the workgroup's bodies, select-on-
 // result instead of the masked FMA when a record is not finite, z chains only when some z is non-zero.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBpcConsumers = 8;
 constexpr int kBpcProducers = 8;
 constexpr int kBpcThreads = (kBpcConsumers + kBpcProducers) * 64;
-constexpr int kBpcChunk = kBpcProducers * 4;  // 32
-constexpr int kBpcStride = kBpcChunk + 4;
-constexpr int kBpcTile = 256;
+constexpr int kBpcPer = 8;                          // consecutive j's per producer per chunk
+constexpr int kBpcChunk = kBpcProducers * kBpcPer;  // 64
+constexpr int kBpcStride = kBpcChunk + 8;           // halfs per body row: 144 B, rows stay 16-B aligned and spread over the banks
+constexpr int kBpcTile = 512;
 constexpr int kBpcChunksPerTile = kBpcTile / kBpcChunk;  // 8
 
+// The masks are 0, 1 or -1: exact in binary16, and v_fma_mix_f32 takes a binary16 multiplicand straight into an fp32 FMA,
+// so half-width masks cost the consumers nothing and let a chunk (one barrier) cover 64 j's in the same 54 KB of LDS.
 struct BpcRing {
-    float m[3][64][kBpcStride];  // masks of rule 1, 2 (negated), 3: [plane][body][j within chunk]
+    _Float16 m[3][64][kBpcStride];  // masks of rule 1, 2 (negated), 3: [plane][body][j within chunk]
 };
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 struct BpcTile {
     float c[6][kBpcTile];  // px, py, pz, vx, vy, vz
 };
 enum BpcSrc { kSrcPx = 0, kSrcPy = 1, kSrcPz = 2, kSrcVx = 3, kSrcVy = 4, kSrcVz = 5, kSrcDx = 6, kSrcDy = 7, kSrcDz = 8, kSrcOne = 9 };
 
-// the three masks of 4 consecutive j's for this lane's body
+// the three masks of 8 consecutive j's for this lane's body
 template <bool SELF, bool PLANAR>
 __device__ __forceinline__ void bpc_produce(const BpcTile &t, int jt, uint32_t jglobal, uint32_t gn, const float4 pn, const float4 vn,
                                             float r1, float t2, float t3, BpcRing &ring, int j0, int lane)
 {
-    const float4 px = *reinterpret_cast<const float4 *>(&t.c[kSrcPx][jt]), py = *reinterpret_cast<const float4 *>(&t.c[kSrcPy][jt]);
-    const float4 vx = *reinterpret_cast<const float4 *>(&t.c[kSrcVx][jt]), vy = *reinterpret_cast<const float4 *>(&t.c[kSrcVy][jt]);
-    float4 pz = make_float4(0.f, 0.f, 0.f, 0.f), vz = pz;
-    if (!PLANAR) {
-        pz = *reinterpret_cast<const float4 *>(&t.c[kSrcPz][jt]);
-        vz = *reinterpret_cast<const float4 *>(&t.c[kSrcVz][jt]);
-    }
-    const float pxs[4] = {px.x, px.y, px.z, px.w}, pys[4] = {py.x, py.y, py.z, py.w}, pzs[4] = {pz.x, pz.y, pz.z, pz.w};
-    const float vxs[4] = {vx.x, vx.y, vx.z, vx.w}, vys[4] = {vy.x, vy.y, vy.z, vy.w}, vzs[4] = {vz.x, vz.y, vz.z, vz.w};
-    float m1[4], m2[4], m3[4];
+    float pxs[kBpcPer], pys[kBpcPer], pzs[kBpcPer], vxs[kBpcPer], vys[kBpcPer], vzs[kBpcPer];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int q = 0; q < kBpcPer / 4; ++q) {
+        const float4 px = *reinterpret_cast<const float4 *>(&t.c[kSrcPx][jt + 4 * q]);
+        const float4 py = *reinterpret_cast<const float4 *>(&t.c[kSrcPy][jt + 4 * q]);
+        const float4 vx = *reinterpret_cast<const float4 *>(&t.c[kSrcVx][jt + 4 * q]);
+        const float4 vy = *reinterpret_cast<const float4 *>(&t.c[kSrcVy][jt + 4 * q]);
+        float4 pz = make_float4(0.f, 0.f, 0.f, 0.f), vz = pz;
+        if (!PLANAR) {
+            pz = *reinterpret_cast<const float4 *>(&t.c[kSrcPz][jt + 4 * q]);
+            vz = *reinterpret_cast<const float4 *>(&t.c[kSrcVz][jt + 4 * q]);
+        }
+        pxs[4 * q] = px.x, pxs[4 * q + 1] = px.y, pxs[4 * q + 2] = px.z, pxs[4 * q + 3] = px.w;
+        pys[4 * q] = py.x, pys[4 * q + 1] = py.y, pys[4 * q + 2] = py.z, pys[4 * q + 3] = py.w;
+        pzs[4 * q] = pz.x, pzs[4 * q + 1] = pz.y, pzs[4 * q + 2] = pz.z, pzs[4 * q + 3] = pz.w;
+        vxs[4 * q] = vx.x, vxs[4 * q + 1] = vx.y, vxs[4 * q + 2] = vx.z, vxs[4 * q + 3] = vx.w;
+        vys[4 * q] = vy.x, vys[4 * q + 1] = vy.y, vys[4 * q + 2] = vy.z, vys[4 * q + 3] = vy.w;
+        vzs[4 * q] = vz.x, vzs[4 * q + 1] = vz.y, vzs[4 * q + 2] = vz.z, vzs[4 * q + 3] = vz.w;
+    }
+    half8 m1, m2, m3;
+#pragma unroll
+    for (int u = 0; u < kBpcPer; ++u) {
         const bool ne = SELF ? (jglobal + (uint32_t)u != gn) : true;          // main.rs:475 n != i
         const float dx = pxs[u] - pn.x, dy = pys[u] - pn.y;
         float d2 = (dx * dx) + (dy * dy);
@@ -621,45 +636,44 @@ __device__ __forceinline__ void bpc_produce(const BpcTile &t, int jt, uint32_t j
             const float ez = vzs[u] - vn.z;
             e2 = e2 + (ez * ez);
         }
-        m1[u] = ((d2 < r1) && ne) ? 1.f : 0.f;    // main.rs:474-475
-        m2[u] = ((d2 <= t2) && ne) ? -1.f : 0.f;  // main.rs:485-486 (negated: repel SUBTRACTS)
-        m3[u] = ((e2 <= t3) && ne) ? 1.f : 0.f;   // main.rs:497-498
+        m1[u] = ((d2 < r1) && ne) ? (_Float16)1.0f : (_Float16)0.0f;    // main.rs:474-475
+        m2[u] = ((d2 <= t2) && ne) ? (_Float16)-1.0f : (_Float16)0.0f;  // main.rs:485-486 (negated: repel SUBTRACTS)
+        m3[u] = ((e2 <= t3) && ne) ? (_Float16)1.0f : (_Float16)0.0f;   // main.rs:497-498
     }
-    *reinterpret_cast<float4 *>(&ring.m[0][lane][j0]) = make_float4(m1[0], m1[1], m1[2], m1[3]);
-    *reinterpret_cast<float4 *>(&ring.m[1][lane][j0]) = make_float4(m2[0], m2[1], m2[2], m2[3]);
-    *reinterpret_cast<float4 *>(&ring.m[2][lane][j0]) = make_float4(m3[0], m3[1], m3[2], m3[3]);
+    *reinterpret_cast<half8 *>(&ring.m[0][lane][j0]) = m1;
+    *reinterpret_cast<half8 *>(&ring.m[1][lane][j0]) = m2;
+    *reinterpret_cast<half8 *>(&ring.m[2][lane][j0]) = m3;
 }
 
 // One chain over one chunk: sum = sum (+) mask_j * src_j for j = 0..nvalid-1 in order.  MASKED: fma form (finite data);
 // else select-on-result.  src: a tile plane, a difference to the own coordinate (repel), or the constant 1 (counts).
+// 16 j's per trip: two 16-byte mask reads (8 halfs each) and four 16-byte source reads.
 template <int SRC, bool MASKED>
-__device__ __forceinline__ void bpc_chain(const float (*mrow)[kBpcStride], const BpcTile &t, int jt, float own, int lane, int nvalid,
+__device__ __forceinline__ void bpc_chain(const _Float16 (*mrow)[kBpcStride], const BpcTile &t, int jt, float own, int lane, int nvalid,
                                           float &sum)
 {
     constexpr int plane = SRC == kSrcOne ? 0 : SRC >= kSrcDx ? SRC - kSrcDx : SRC;
 #pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        float4 mk[4], sv[4];
+    for (int h = 0; h < kBpcChunk / 16; ++h) {
+        half8 mk[2];
+        float4 sv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            mk[g] = *reinterpret_cast<const float4 *>(&mrow[lane][16 * h + 4 * g]);
+        for (int g = 0; g < 2; ++g) mk[g] = *reinterpret_cast<const half8 *>(&mrow[lane][16 * h + 8 * g]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
             sv[g] = SRC != kSrcOne ? *reinterpret_cast<const float4 *>(&t.c[plane][jt + 16 * h + 4 * g]) : make_float4(1.f, 1.f, 1.f, 1.f);
-        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float ms[4] = {mk[g].x, mk[g].y, mk[g].z, mk[g].w};
-            const float ss[4] = {sv[g].x, sv[g].y, sv[g].z, sv[g].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (16 * h + 4 * g + u >= nvalid) continue;  // uniform; only the last chunk of the set is short
-                float x = SRC == kSrcOne ? 1.f : ss[u];
-                if (SRC >= kSrcDx && SRC <= kSrcDz) x = x - own;  // p_i - p_n
-                if (MASKED) {
-                    sum = SRC == kSrcOne ? sum + ms[u] : __builtin_fmaf(ms[u], x, sum);
-                } else {  // select on the result: a skipped term leaves the sum untouched whatever x is
-                    const float cand = (SRC >= kSrcDx && SRC <= kSrcDz) ? sum - x : sum + x;
-                    sum = (ms[u] != 0.f) ? cand : sum;
-                }
+        for (int u = 0; u < 16; ++u) {
+            if (16 * h + u >= nvalid) continue;  // uniform; only the last chunk of the set is short
+            const _Float16 mh = mk[u / 8][u % 8];
+            const float4 v4 = sv[u / 4];
+            float x = (u % 4) == 0 ? v4.x : (u % 4) == 1 ? v4.y : (u % 4) == 2 ? v4.z : v4.w;
+            if (SRC >= kSrcDx && SRC <= kSrcDz) x = x - own;  // p_i - p_n
+            if (MASKED) {
+                sum = SRC == kSrcOne ? sum + (float)mh : __builtin_fmaf((float)mh, x, sum);
+            } else {  // select on the result: a skipped term leaves the sum untouched whatever x is
+                const float cand = (SRC >= kSrcDx && SRC <= kSrcDz) ? sum - x : sum + x;
+                sum = (mh != (_Float16)0.0f) ? cand : sum;
             }
         }
     }
@@ -708,7 +722,9 @@ __global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
     __shared__ __attribute__((aligned(16))) BpcTile tile[2];
     __shared__ __attribute__((aligned(16))) BpcRing ring[2];
     __shared__ uint32_t tile_flags[2][8];
-    __shared__ float sums[11][64];
+    // the 11 final sums per body are handed to wave 0 through ring[0]'s storage once every fold is done (keeps the
+    // workgroup under 80 KiB of LDS, i.e. two workgroups per CU)
+    float(*sums)[64] = reinterpret_cast<float(*)[64]>(&ring[0]);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -726,26 +742,32 @@ __global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
 
     const uint32_t n = a.n_total;
     const uint32_t ntiles = (n + (uint32_t)kBpcTile - 1u) / (uint32_t)kBpcTile;
-    // loaders: producer waves 8..11 stage positions, 12..15 velocities (one record per thread)
+    // loaders: the 512 threads of the producer waves stage one position and one velocity record each
     const int ltid = tid - kBpcConsumers * 64;
-    const bool loads_pos = ltid >= 0 && ltid < kBpcTile, loads_vel = ltid >= kBpcTile && ltid < 2 * kBpcTile;
-    auto fetch = [&](uint32_t t) -> float4 {
-        const uint32_t j = t * (uint32_t)kBpcTile + (uint32_t)(ltid & (kBpcTile - 1));
-        if (loads_pos && j < n) return a.pos_in[j];
-        if (loads_vel && j < n) return a.vel_in[j];
-        return make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool loader = ltid >= 0;
+    struct Staged {
+        float4 p, v;
     };
-    auto publish = [&](int buf, float4 rec) {
-        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));  // keep the flag arithmetic at the use point
-        if (loads_pos || loads_vel) {
-            const int k = ltid & (kBpcTile - 1), base = loads_pos ? 0 : 3;
-            tile[buf].c[base + 0][k] = rec.x;
-            tile[buf].c[base + 1][k] = rec.y;
-            tile[buf].c[base + 2][k] = rec.z;
-            auto nonfinite = [](float c) { return (__float_as_uint(c) & 0x7f800000u) == 0x7f800000u ? kBoidsNonFinite : 0u; };
-            uint32_t f = nonfinite(rec.x) | nonfinite(rec.y) | nonfinite(rec.z) |
-                         ((__float_as_uint(rec.z) & 0x7fffffffu) != 0u ? kBoidsNonPlanar : 0u);
-            f = wave_flags(f);
+    auto fetch = [&](uint32_t t) -> Staged {
+        Staged r = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        const uint32_t j = t * (uint32_t)kBpcTile + (uint32_t)(loader ? ltid : 0);
+        if (loader && j < n) {
+            r.p = a.pos_in[j];
+            r.v = a.vel_in[j];
+        }
+        return r;
+    };
+    auto publish = [&](int buf, Staged rec) {
+        // keep the flag arithmetic (pure, on prefetched data) at the use point instead of right behind the loads
+        asm volatile("" : "+v"(rec.p.x), "+v"(rec.p.y), "+v"(rec.p.z), "+v"(rec.p.w), "+v"(rec.v.x), "+v"(rec.v.y), "+v"(rec.v.z), "+v"(rec.v.w));
+        if (loader) {
+            tile[buf].c[kSrcPx][ltid] = rec.p.x;
+            tile[buf].c[kSrcPy][ltid] = rec.p.y;
+            tile[buf].c[kSrcPz][ltid] = rec.p.z;
+            tile[buf].c[kSrcVx][ltid] = rec.v.x;
+            tile[buf].c[kSrcVy][ltid] = rec.v.y;
+            tile[buf].c[kSrcVz][ltid] = rec.v.z;
+            const uint32_t f = wave_flags(boids_flags(rec.p, rec.v));
             if (lane == 0) tile_flags[buf][wave - kBpcConsumers] = f;
         }
     };
@@ -801,6 +823,7 @@ __global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
         const int tb = (int)((ntiles - 1u) & 1u), k = last_nk - 1;
         const uint32_t first_j = (ntiles - 1u) * (uint32_t)kBpcTile + (uint32_t)k * (uint32_t)kBpcChunk;
         bpc_fold_flags<ROLE>(prev_flags, ring[k & 1], tile[tb], k * kBpcChunk, pn, lane, (int)(n - first_j), sum_a, sum_b);
+        __syncthreads();  // every consumer is done with the ring: its storage now carries the sums (producers match this barrier)
         sums[ROLE][lane] = sum_a;
         if (ROLE == 2) sums[8][lane] = sum_b;   // centre z
         if (ROLE == 3) sums[9][lane] = sum_b;   // repel z
@@ -809,10 +832,10 @@ __global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
 
     // ---- producer waves ------------------------------------------------------------------------------------
     auto producer = [&]() {
-        const int j0 = (wave - kBpcConsumers) * 4;
+        const int j0 = (wave - kBpcConsumers) * kBpcPer;
         for (uint32_t t = 0; t < ntiles; ++t) {
             const TileInfo ti = tile_info(t);
-            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            Staged rec = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             if (ti.stage) rec = fetch(t + 1u);  // in flight across the chunks of this tile
             auto stage_next = [&]() {
                 if (ti.stage) publish(ti.tb ^ 1, rec);  // tile t+1 goes to the buffer tile t-1 used
@@ -833,6 +856,7 @@ __global__ __launch_bounds__(kBpcThreads) void boids_pc_kernel(BoidsArgs a)
                 if (planar) run(F{}, T{}); else run(F{}, F{});
             }
         }
+        __syncthreads();  // matches the consumers' barrier in front of the sums hand-off
     };
 
     switch (wave) {
