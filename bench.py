@@ -97,6 +97,9 @@ def main():
                     help="arithmetic of the headline number: strict = bit-identical to the reference (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip timing the other mode")
+    ap.add_argument("--aux-timeout", type=float, default=180.0,
+                    help="seconds the informational legs (other mode, boids, CPU baseline) may take before the headline is "
+                         "printed without them")
     args = ap.parse_args()
 
     import torch
@@ -127,39 +130,6 @@ def main():
     pos, vel = nb.init_state(n, 1234)
     primary = nb.NB_MODE_STRICT if args.mode == "strict" else nb.NB_MODE_FAST
     res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel)
-    other = None
-    other_error = None
-    if not args.no_secondary:
-        other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
-        try:  # informational: must never cost the headline line
-            other = time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel)
-        except Exception as e:  # pragma: no cover
-            other_error = repr(e)
-
-    # Informational: the boids controller (update_instance_boids, main.rs:443-526), same set
-    # and sharding.  Never the headline; a failure here must not cost the n-body line.
-    boids = None
-    try:
-        sc = nb.ShardedScene(pos, vel)
-        for _ in range(2):
-            sc.step_boids()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        bsteps = max(2, min(args.steps, 10))
-        t0 = time.perf_counter()
-        for _ in range(bsteps):
-            sc.step_boids()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
-        if world > 1:
-            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-        boids = {"metric": "body-updates/s, update_instance_boids (bit-exact)", "value": n * bsteps / float(bt.item()),
-                 "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
-    except Exception as e:  # pragma: no cover
-        boids = {"error": repr(e)}
 
     def summarise(r):
         steps_per_s = args.steps / r["elapsed_s"]
@@ -178,44 +148,86 @@ def main():
                          "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"]},
         }
 
-    if rank == 0:
-        s = summarise(res)
-        line = {
-            "metric": f"body-updates/sec (N x steps/s) at N={n}, all-pairs gravity + Euler step",
-            "value": s["body_updates_per_s"],
-            "unit": "body-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": s["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL backend, not a measurement)",
-            "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234), dt=0.1 G=0.001 bias=1e-7",
-                       "mode": args.mode, "sharding": f"index range x{world}, all-gather of positions per step",
-                       "tile": "library default"},
-            "interactions_per_s": s["interactions_per_s"],
-            "roofline": s["roofline"],
-        }
-        if other_error is not None:
-            line["other_mode"] = {"error": other_error}
-        if other is not None:
-            o = summarise(other)
+    s = summarise(res)
+    line = {
+        "metric": f"body-updates/sec (N x steps/s) at N={n}, all-pairs gravity + Euler step",
+        "value": s["body_updates_per_s"],
+        "unit": "body-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": s["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL backend, not a measurement)",
+        "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234), dt=0.1 G=0.001 bias=1e-7",
+                   "mode": args.mode, "sharding": f"index range x{world}, all-gather of positions per step",
+                   "tile": "library default"},
+        "interactions_per_s": s["interactions_per_s"],
+        "roofline": s["roofline"],
+    }
+
+    # Everything after this point is informational.  If it wedges (a collective that never completes, say), the
+    # headline measured above must still be reported: the watchdog prints it and ends this rank.
+    import threading
+
+    def give_up():  # pragma: no cover
+        if rank == 0:
+            line["aux_error"] = f"informational legs did not finish within {args.aux_timeout} s"
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.aux_timeout, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
+    if not args.no_secondary:
+        other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
+        try:
+            o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel))
             line["other_mode"] = {"mode": "fast" if primary == nb.NB_MODE_STRICT else "strict",
                                   "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
-        line["boids_controller"] = boids
-        if world == 1 and not args.no_cpu_baseline:
-            import oracle  # cpu_baseline leg: the oracle is timed here, never used by the product path
+        except Exception as e:  # pragma: no cover
+            line["other_mode"] = {"error": repr(e)}
 
-            cores = oracle.ncores()
-            t0 = time.perf_counter()
-            oracle.run(pos, vel, 1, threads=cores)
-            dt = time.perf_counter() - t0
-            line["cpu_baseline"] = {"value": n / dt, "unit": "body-updates/s", "cores": cores, "kind": "port",
-                                    "sample": f"1 full step of the same N={n} workload ({n * n:.3e} interactions), all host cores, "
-                                              "C restatement of src/main.rs:404-441 (-O2 -ffp-contract=off)",
-                                    "seconds": dt}
-        print(json.dumps(line))
+    # the boids controller (update_instance_boids, main.rs:443-526), same set and sharding
+    try:
+        sc = nb.ShardedScene(pos, vel)
+        for _ in range(2):
+            sc.step_boids()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        bsteps = max(2, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(bsteps):
+            sc.step_boids()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
+        if world > 1:
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        line["boids_controller"] = {"metric": "body-updates/s, update_instance_boids (bit-exact)",
+                                    "value": n * bsteps / float(bt.item()),
+                                    "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
+    except Exception as e:  # pragma: no cover
+        line["boids_controller"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle  # cpu_baseline leg: the oracle is timed here, never used by the product path
+
+        cores = oracle.ncores()
+        t0 = time.perf_counter()
+        oracle.run(pos, vel, 1, threads=cores)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": n / dt, "unit": "body-updates/s", "cores": cores, "kind": "port",
+                                "sample": f"1 full step of the same N={n} workload ({n * n:.3e} interactions), all host cores, "
+                                          "C restatement of src/main.rs:404-441 (-O2 -ffp-contract=off)",
+                                "seconds": dt}
+    watchdog.cancel()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,6 +148,29 @@ int nb_sync(nb_ctx *ctx);
 /* Steps taken since nb_upload. */
 uint64_t nb_steps_done(const nb_ctx *ctx);
 
+/* -- one-call drop-ins: the reference's free functions themselves ------------------------------------- *
+ * `update_instance_nbody(instances, positions, old_positions, velocities, old_velocities)` (src/main.rs:404-410) and
+ * `update_instance_boids` (src/main.rs:443-449) with their own five slices, updated in place; every length is the
+ * slice's len() in elements (bodies).  A maintainer replaces each function body by one call.
+ * Kept from the reference:
+ *   - old_positions / old_velocities receive copies of positions / velocities first (main.rs:415-416, 459-460);
+ *     unequal lengths are NB_ERR_INVALID, where copy_from_slice panics;
+ *   - instances.zip(positions).zip(velocities) stops at the shortest (main.rs:420-423, 465-469): only that many
+ *     bodies are written, while the folds still run over all of old_positions;
+ *   - boids reads old_velocities[i] for every i < len(old_positions) (main.rs:494-504): a shorter velocity slice
+ *     is NB_ERR_INVALID, where the reference indexes out of bounds and panics.
+ * One upload, one step, one download per call.  The device context lives inside the library between calls and is
+ * rebuilt when the body count or the constants change; calls are serialised by an internal lock.
+ * params == NULL -> the reference constants. */
+int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                             float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
+                             float *old_velocities_xyz, size_t n_old_velocities, const nb_params *params);
+int nb_update_instance_boids(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                             float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
+                             float *old_velocities_xyz, size_t n_old_velocities, const nb_boids_params *params);
+/* Frees the context the two calls above keep (otherwise it is reclaimed with the process). */
+void nb_update_release(void);
+
 /* Diagnostic: checks on the GPU that STRICT's shared-reciprocal division ladder equals the IEEE binary32 divide on
  * `pairs` random (numerator, denominator) pairs drawn over the whole exponent rectangle the range guard admits for
  * `params` (NULL = defaults), structured mantissas included.  *mismatches receives the number of differing results

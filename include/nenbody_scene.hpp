@@ -95,23 +95,37 @@ private:
     nb_ctx *ctx_ = nullptr;
 };
 
-// Drop-in for the reference's free function, src/main.rs:404-410: one upload, one step, one download per call.
-inline void update_instance_nbody(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &old_positions,
-                                  std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities)
+// Drop-ins for the reference's free functions, src/main.rs:404-410 and 443-449: same five arguments, updated in place,
+// one FFI call each (nb_update_instance_nbody / nb_update_instance_boids keep the device context between calls).
+// A length mismatch is where copy_from_slice panics (src/main.rs:415-416): std::invalid_argument here.
+namespace detail {
+inline void update_status(int rc)
 {
-    if (old_positions.size() != positions.size() || old_velocities.size() != velocities.size())
-        throw std::invalid_argument("source slice length does not match destination slice length");  // copy_from_slice
-    old_positions = positions;    // src/main.rs:415
-    old_velocities = velocities;  // src/main.rs:416
-    const size_t count = std::min({instances.size(), positions.size(), velocities.size()});  // zip, src/main.rs:420-423
-    if (count == 0) return;
-    std::vector<Vec3> vel_full = velocities;
-    vel_full.resize(positions.size(), Vec3{0.f, 0.f, 0.f});  // bodies past the zip are computed and dropped
-    Scene scene(old_positions, vel_full, default_params());
-    scene.step();
-    std::copy_n(scene.positions.begin(), count, positions.begin());
-    std::copy_n(scene.velocities.begin(), count, velocities.begin());
-    std::copy_n(scene.instances.begin(), count, instances.begin());
+    if (rc == NB_ERR_INVALID) throw std::invalid_argument(nb_last_error(nullptr));
+    check(rc, nullptr);
+}
+inline float *ptr(std::vector<Vec3> &v) { return v.empty() ? nullptr : v[0].data(); }
+inline float *ptr(std::vector<Mat4> &v) { return v.empty() ? nullptr : v[0][0].data(); }
+}  // namespace detail
+
+inline void update_instance_nbody(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &old_positions,
+                                  std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities,
+                                  const nb_params *params = nullptr)
+{
+    detail::update_status(nb_update_instance_nbody(detail::ptr(instances), instances.size(), detail::ptr(positions),
+                                                   positions.size(), detail::ptr(old_positions), old_positions.size(),
+                                                   detail::ptr(velocities), velocities.size(), detail::ptr(old_velocities),
+                                                   old_velocities.size(), params));
+}
+
+inline void update_instance_boids(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &old_positions,
+                                  std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities,
+                                  const nb_boids_params *params = nullptr)
+{
+    detail::update_status(nb_update_instance_boids(detail::ptr(instances), instances.size(), detail::ptr(positions),
+                                                   positions.size(), detail::ptr(old_positions), old_positions.size(),
+                                                   detail::ptr(velocities), velocities.size(), detail::ptr(old_velocities),
+                                                   old_velocities.size(), params));
 }
 
 }  // namespace nenbody

@@ -50,6 +50,17 @@ extern "C" {
     fn nb_step_boids(ctx: *mut NbCtx, k: u32, params: *const NbBoidsParams) -> c_int; // null = reference constants
     fn nb_download(ctx: *mut NbCtx, pos_xyz: *mut f32, vel_xyz: *mut f32, inst_16n: *mut f32) -> c_int;
     fn nb_sync(ctx: *mut NbCtx) -> c_int;
+    // the reference's free functions themselves: five slices and their lengths, params null = reference constants
+    fn nb_update_instance_nbody(
+        instances: *mut f32, n_instances: usize, positions: *mut f32, n_positions: usize,
+        old_positions: *mut f32, n_old_positions: usize, velocities: *mut f32, n_velocities: usize,
+        old_velocities: *mut f32, n_old_velocities: usize, params: *const NbParams,
+    ) -> c_int;
+    fn nb_update_instance_boids(
+        instances: *mut f32, n_instances: usize, positions: *mut f32, n_positions: usize,
+        old_positions: *mut f32, n_old_positions: usize, velocities: *mut f32, n_velocities: usize,
+        old_velocities: *mut f32, n_old_velocities: usize, params: *const NbBoidsParams,
+    ) -> c_int;
 }
 
 impl Default for NbParams {
@@ -158,8 +169,10 @@ impl Drop for Scene {
     }
 }
 
-/// Drop-in for the reference's free function (same five arguments, src/main.rs:404-410): one upload, one step,
-/// one download per call.  A caller that steps every frame should hold a `Scene` instead.
+/// Drop-in for the reference's free function (same five arguments, src/main.rs:404-410): the body is one FFI call.
+/// The snapshot copies (src/main.rs:415-416), the `zip` truncation (src/main.rs:420-423) and the fold over all of
+/// `old_positions` happen inside `nb_update_instance_nbody`; a length mismatch panics here as `copy_from_slice`
+/// does there.  One upload, one step, one download per call; the device context is kept by the library.
 pub fn update_instance_nbody(
     instances: &mut Vec<[[f32; 4]; 4]>,
     positions: &mut Vec<Point3<f32>>,
@@ -167,17 +180,40 @@ pub fn update_instance_nbody(
     velocities: &mut Vec<Vector3<f32>>,
     old_velocities: &mut Vec<Vector3<f32>>,
 ) {
-    old_positions.copy_from_slice(positions.as_slice()); // src/main.rs:415 (panics on a length mismatch)
-    old_velocities.copy_from_slice(velocities.as_slice()); // src/main.rs:416
-    let count = instances.len().min(positions.len()).min(velocities.len()); // zip, src/main.rs:420-423
-    if count == 0 {
-        return;
+    let rc = unsafe {
+        nb_update_instance_nbody(
+            instances.as_mut_ptr() as *mut f32, instances.len(),
+            positions.as_mut_ptr() as *mut f32, positions.len(),
+            old_positions.as_mut_ptr() as *mut f32, old_positions.len(),
+            velocities.as_mut_ptr() as *mut f32, velocities.len(),
+            old_velocities.as_mut_ptr() as *mut f32, old_velocities.len(),
+            std::ptr::null(),
+        )
+    };
+    if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
+        panic!("update_instance_nbody: {} ({})", msg, code);
     }
-    let mut vel_full = velocities.clone();
-    vel_full.resize(positions.len(), Vector3::new(0.0, 0.0, 0.0)); // bodies past the zip are computed and dropped
-    let mut scene = Scene::from_state(old_positions.clone(), vel_full, NbParams::default()).expect("nenbody_hip");
-    scene.step().expect("nenbody_hip step");
-    positions[..count].copy_from_slice(&scene.positions[..count]);
-    velocities[..count].copy_from_slice(&scene.velocities[..count]);
-    instances[..count].copy_from_slice(&scene.instances[..count]);
+}
+
+/// The controller the event loop calls today (src/main.rs:443-449, call site src/main.rs:925-931), same contract.
+pub fn update_instance_boids(
+    instances: &mut Vec<[[f32; 4]; 4]>,
+    positions: &mut Vec<Point3<f32>>,
+    old_positions: &mut Vec<Point3<f32>>,
+    velocities: &mut Vec<Vector3<f32>>,
+    old_velocities: &mut Vec<Vector3<f32>>,
+) {
+    let rc = unsafe {
+        nb_update_instance_boids(
+            instances.as_mut_ptr() as *mut f32, instances.len(),
+            positions.as_mut_ptr() as *mut f32, positions.len(),
+            old_positions.as_mut_ptr() as *mut f32, old_positions.len(),
+            velocities.as_mut_ptr() as *mut f32, velocities.len(),
+            old_velocities.as_mut_ptr() as *mut f32, old_velocities.len(),
+            std::ptr::null(),
+        )
+    };
+    if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
+        panic!("update_instance_boids: {} ({})", msg, code);
+    }
 }

@@ -82,6 +82,9 @@ PROTOTYPES = {
     "nb_cameras": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_cameras": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "nb_update_instance_nbody": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbParams)]),
+    "nb_update_instance_boids": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbBoidsParams)]),
+    "nb_update_release": (None, []),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),

@@ -8,8 +8,10 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/nenbody.h"
 #include "nb_kernels.h"
@@ -648,6 +650,126 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
     }
     if (!pos_xyz && !vel_xyz && !inst_16n) NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NB_OK;
+}
+
+// ---- one-call drop-ins (src/main.rs:404-410, 443-449) ---------------------------------------------------
+namespace {
+struct UpdateCache {
+    std::mutex mu;
+    nb_ctx *ctx = nullptr;
+    nb_params p{};
+    std::vector<float> vel_full, pos_tmp, vel_tmp, inst_tmp;
+};
+// never destroyed: a static destructor could run after the HIP runtime's own teardown
+UpdateCache &update_cache()
+{
+    static UpdateCache *c = new UpdateCache();
+    return *c;
+}
+
+int update_fail(UpdateCache &uc, const char *who, int rc)
+{
+    g_tls_error = std::string(who) + ": " + (uc.ctx ? uc.ctx->err : g_tls_error);
+    return rc;
+}
+
+int update_common(const char *who, bool boids, float *inst, size_t n_inst, float *pos, size_t n_pos, float *opos, size_t n_opos,
+                  float *vel, size_t n_vel, float *ovel, size_t n_ovel, const nb_params *np, const nb_boids_params *bp)
+{
+    if (n_opos != n_pos || n_ovel != n_vel) {  // copy_from_slice (main.rs:415-416, 459-460) panics
+        g_tls_error = std::string(who) + ": source slice length does not match destination slice length (" +
+                      (n_opos != n_pos ? "old_positions vs positions" : "old_velocities vs velocities") + ")";
+        return NB_ERR_INVALID;
+    }
+    if ((n_pos && (!pos || !opos)) || (n_vel && (!vel || !ovel)) || (n_inst && !inst)) {
+        g_tls_error = std::string(who) + ": null array with a nonzero length";
+        return NB_ERR_INVALID;
+    }
+    const size_t xyz = 3 * sizeof(float);
+    if (n_pos) std::memcpy(opos, pos, n_pos * xyz);  // main.rs:415 / 459
+    if (n_vel) std::memcpy(ovel, vel, n_vel * xyz);  // main.rs:416 / 460
+    const size_t count = std::min(n_inst, std::min(n_pos, n_vel));  // zip, main.rs:420-423 / 465-469
+    if (count == 0) return NB_OK;
+    if (n_pos > 0xffffffffull) {
+        g_tls_error = std::string(who) + ": more than 2^32-1 bodies";
+        return NB_ERR_INVALID;
+    }
+    if (boids && n_vel < n_pos) {  // old_velocities[n] for every n < old_positions.len(), main.rs:494-496
+        g_tls_error = std::string(who) + ": velocities shorter than positions (the reference indexes old_velocities out of bounds)";
+        return NB_ERR_INVALID;
+    }
+    nb_params p;
+    if (np)
+        p = *np;
+    else
+        nb_default_params(&p);
+
+    UpdateCache &uc = update_cache();
+    std::lock_guard<std::mutex> lock(uc.mu);
+    const uint32_t n = (uint32_t)n_pos;
+    if (!uc.ctx || uc.ctx->n != n || std::memcmp(&uc.p, &p, sizeof(p)) != 0) {
+        if (uc.ctx) nb_destroy(uc.ctx);
+        uc.ctx = nullptr;
+        int rc = nb_create(n, 1, &p, &uc.ctx);
+        if (rc != NB_OK) return update_fail(uc, who, rc);
+        uc.p = p;
+    }
+    const float *vel_src = ovel;
+    if (n_vel < n_pos) {  // n-body only: bodies past the zip are computed and dropped; give them a velocity to carry
+        uc.vel_full.assign(n_pos * 3, 0.f);
+        std::memcpy(uc.vel_full.data(), ovel, n_vel * xyz);
+        vel_src = uc.vel_full.data();
+    }
+    int rc = nb_upload(uc.ctx, opos, vel_src);
+    if (rc == NB_OK) rc = boids ? nb_step_boids(uc.ctx, 1, bp) : nb_step(uc.ctx, 1);
+    if (rc != NB_OK) return update_fail(uc, who, rc);
+    if (count == n_pos) {  // the usual case: all three slices as long as the set
+        rc = nb_download(uc.ctx, pos, vel, inst);
+        if (rc != NB_OK) return update_fail(uc, who, rc);
+        return NB_OK;
+    }
+    uc.pos_tmp.resize(n_pos * 3);
+    uc.vel_tmp.resize(n_pos * 3);
+    uc.inst_tmp.resize(n_pos * 16);
+    rc = nb_download(uc.ctx, uc.pos_tmp.data(), uc.vel_tmp.data(), uc.inst_tmp.data());
+    if (rc != NB_OK) return update_fail(uc, who, rc);
+    std::memcpy(pos, uc.pos_tmp.data(), count * xyz);
+    std::memcpy(vel, uc.vel_tmp.data(), count * xyz);
+    std::memcpy(inst, uc.inst_tmp.data(), count * 16 * sizeof(float));
+    return NB_OK;
+}
+}  // namespace
+
+NB_EXPORT int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                       float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz,
+                                       size_t n_velocities, float *old_velocities_xyz, size_t n_old_velocities,
+                                       const nb_params *params)
+{
+    return update_common("nb_update_instance_nbody", false, instances_16n, n_instances, positions_xyz, n_positions,
+                         old_positions_xyz, n_old_positions, velocities_xyz, n_velocities, old_velocities_xyz, n_old_velocities,
+                         params, nullptr);
+}
+
+NB_EXPORT int nb_update_instance_boids(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                       float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz,
+                                       size_t n_velocities, float *old_velocities_xyz, size_t n_old_velocities,
+                                       const nb_boids_params *params)
+{
+    return update_common("nb_update_instance_boids", true, instances_16n, n_instances, positions_xyz, n_positions,
+                         old_positions_xyz, n_old_positions, velocities_xyz, n_velocities, old_velocities_xyz, n_old_velocities,
+                         nullptr, params);
+}
+
+NB_EXPORT void nb_update_release(void)
+{
+    UpdateCache &uc = update_cache();
+    std::lock_guard<std::mutex> lock(uc.mu);
+    if (uc.ctx) nb_destroy(uc.ctx);
+    uc.ctx = nullptr;
+    uc.vel_full = std::vector<float>();
+    uc.pos_tmp = std::vector<float>();
+    uc.vel_tmp = std::vector<float>();
+    uc.inst_tmp = std::vector<float>();
 }
 
 NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair)

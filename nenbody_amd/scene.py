@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import NB_MODE_FAST, NB_MODE_STRICT, NbBoidsParams, NbError, NbParams, check  # noqa: F401  (re-exported)
 
-__all__ = ["Scene", "update_instance_nbody", "update_instance_boids", "init_state", "NB_MODE_STRICT", "NB_MODE_FAST",
+__all__ = ["Scene", "update_instance_nbody", "update_instance_boids", "update_release", "init_state", "NB_MODE_STRICT", "NB_MODE_FAST",
            "NbParams", "NbBoidsParams", "NbError"]
 
 
@@ -181,10 +181,17 @@ def _check_update_args(instances, positions, old_positions, velocities, old_velo
             raise TypeError(f"{name} must be a writable C-contiguous float32 numpy array")
         if arr.ndim != len(tail) + 1 or tuple(arr.shape[1:]) != tail:
             raise ValueError(f"{name} must have shape (n, {', '.join(map(str, tail))})")
-    if len(old_positions) != len(positions):
-        raise ValueError("source slice length does not match destination slice length (old_positions vs positions)")
-    if len(old_velocities) != len(velocities):
-        raise ValueError("source slice length does not match destination slice length (old_velocities vs velocities)")
+
+
+def _update_call(fn, instances, positions, old_positions, velocities, old_velocities, params):
+    _check_update_args(instances, positions, old_positions, velocities, old_velocities)
+    args = []
+    for arr in (instances, positions, old_positions, velocities, old_velocities):
+        args += [arr.ctypes.data if len(arr) else None, len(arr)]
+    rc = fn(*args, ctypes.byref(params) if params is not None else None)
+    if rc == _lib.NB_ERR_INVALID:  # the reference panics here (copy_from_slice, indexing); in Python that is a ValueError
+        raise ValueError(_lib.load().nb_last_error(None).decode())
+    check(rc)
 
 
 def update_instance_boids(instances, positions, old_positions, velocities, old_velocities,
@@ -193,22 +200,10 @@ def update_instance_boids(instances, positions, old_positions, velocities, old_v
 
     Same contract as :func:`update_instance_nbody` (snapshot copies first, main.rs:459-460; `zip` stops at the
     shortest of instances / positions / velocities, main.rs:465-469).  The velocity fold (main.rs:494-504) reads
-    ``old_velocities`` for every body, so ``velocities`` must be as long as ``positions`` here.
+    ``old_velocities[n]`` for every body, so ``velocities`` may not be shorter than ``positions``.
+    One call of ``nb_update_instance_boids`` (include/nenbody.h).
     """
-    _check_update_args(instances, positions, old_positions, velocities, old_velocities)
-    old_positions[...] = positions   # main.rs:459
-    old_velocities[...] = velocities  # main.rs:460
-    count = min(len(instances), len(positions), len(velocities))
-    if count == 0:
-        return
-    if len(velocities) != len(positions):
-        raise ValueError("update_instance_boids: positions and velocities must have the same length "
-                         "(the reference would index old_velocities by the enumerate() of a longer zip)")
-    with Scene(old_positions, old_velocities) as sc:
-        sc.step_boids(params)
-        positions[:count] = sc._positions[:count]
-        velocities[:count] = sc._velocities[:count]
-        instances[:count] = sc._instances[:count]
+    _update_call(_lib.load().nb_update_instance_boids, instances, positions, old_positions, velocities, old_velocities, params)
 
 
 def update_instance_nbody(instances, positions, old_positions, velocities, old_velocities,
@@ -221,22 +216,13 @@ def update_instance_nbody(instances, positions, old_positions, velocities, old_v
         mismatch is an error, as ``copy_from_slice`` panics;
       * ``instances.zip(positions).zip(velocities)`` stops at the shortest of the three (main.rs:420-423):
         only that many bodies are updated, while the fold still runs over all of ``old_positions``.
-    One upload, one step, one download per call: this is the drop-in form, not the fast one -- a caller
-    that steps repeatedly should hold a :class:`Scene`.
+    One call of ``nb_update_instance_nbody`` (include/nenbody.h): one upload, one step, one download; the device context
+    is kept inside the library between calls.  A caller that steps repeatedly without reading the state back should
+    hold a :class:`Scene` instead.
     """
-    _check_update_args(instances, positions, old_positions, velocities, old_velocities)
-    old_positions[...] = positions  # main.rs:415
-    old_velocities[...] = velocities  # main.rs:416
-    count = min(len(instances), len(positions), len(velocities))  # zip semantics, main.rs:420-423
-    if count == 0:
-        return
-    n = len(positions)
-    vel_full = velocities
-    if len(velocities) < n:  # bodies past the zip are computed and discarded; give them a velocity to carry
-        vel_full = np.zeros((n, 3), np.float32)
-        vel_full[: len(velocities)] = velocities
-    with Scene(old_positions, vel_full[:n], params) as sc:
-        sc.step()
-        positions[:count] = sc._positions[:count]
-        velocities[:count] = sc._velocities[:count]
-        instances[:count] = sc._instances[:count]
+    _update_call(_lib.load().nb_update_instance_nbody, instances, positions, old_positions, velocities, old_velocities, params)
+
+
+def update_release() -> None:
+    """Frees the device context the two drop-in functions keep between calls."""
+    _lib.load().nb_update_release()

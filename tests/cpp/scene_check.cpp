@@ -13,19 +13,40 @@ int main(int argc, char **argv)
     const uint32_t k = (uint32_t)std::atoi(argv[2]);
     const bool fast = argc > 4 && std::strcmp(argv[4], "fast") == 0;
     try {
-        nenbody::Scene scene(n, nenbody::default_params(fast ? NB_MODE_FAST : NB_MODE_STRICT), 1234);
+        const nb_params prm = nenbody::default_params(fast ? NB_MODE_FAST : NB_MODE_STRICT);
+        nenbody::Scene scene(n, prm, 1234);
         // first k-1 steps device-resident, the last one through step() (refreshes the host mirrors)
         if (k > 1) scene.step_n(k - 1);
         scene.step();
         // and the drop-in form once more on a copy, to check it agrees with Scene::step
         std::vector<nenbody::Vec3> p = scene.positions, v = scene.velocities, op(n), ov(n);
         std::vector<nenbody::Mat4> inst(n);
-        nenbody::update_instance_nbody(inst, p, op, v, ov);
+        nenbody::update_instance_nbody(inst, p, op, v, ov, &prm);
         scene.step();
         if (std::memcmp(p.data(), scene.positions.data(), n * sizeof(nenbody::Vec3)) != 0 ||
             std::memcmp(v.data(), scene.velocities.data(), n * sizeof(nenbody::Vec3)) != 0) {
             std::fprintf(stderr, "update_instance_nbody and Scene::step disagree\n");
             return 3;
+        }
+        // the same for the boids controller (src/main.rs:443-449), on copies: the dumped state stays the n-body one
+        {
+            std::vector<nenbody::Vec3> bp = scene.positions, bv = scene.velocities;
+            nenbody::Scene twin(bp, bv, prm);
+            nenbody::update_instance_boids(inst, bp, op, bv, ov);
+            twin.step_boids();
+            if (std::memcmp(bp.data(), twin.positions.data(), n * sizeof(nenbody::Vec3)) != 0 ||
+                std::memcmp(bv.data(), twin.velocities.data(), n * sizeof(nenbody::Vec3)) != 0 ||
+                std::memcmp(inst.data(), twin.instances.data(), n * sizeof(nenbody::Mat4)) != 0) {
+                std::fprintf(stderr, "update_instance_boids and Scene::step_boids disagree\n");
+                return 5;
+            }
+            try {  // copy_from_slice panics on unequal lengths (src/main.rs:459)
+                std::vector<nenbody::Vec3> too_short(n > 1 ? n - 1 : 2);
+                nenbody::update_instance_boids(inst, bp, too_short, bv, ov);
+                std::fprintf(stderr, "a length mismatch was accepted\n");
+                return 6;
+            } catch (const std::invalid_argument &) {
+            }
         }
         FILE *f = std::fopen(argv[3], "wb");
         if (!f) return 4;

@@ -10,6 +10,10 @@ Layout of nbody_golden.npz (float32, little-endian):
     n16_init_pos/vel, n16_k{1,10}_pos/vel, n16_k10_inst
     n1024_init is regenerated from the seed (not stored); n1024_k{1,10,100,1000}_pos/vel, n1024_k1000_inst
     n16384_k5_sample_idx / _pos / _vel   64 sampled bodies after 5 steps, + float64 checksums of all bodies
+
+Layout of nbody_golden_c2.npz (BASELINE config 2 at the horizons SURVEY.md section 8d names; `--c2`, about 10 minutes
+of CPU on 8 cores):
+    n16384_k{100,1000}_sample_idx / _pos / _vel   64 sampled bodies, + XOR of all position / velocity bit patterns
 """
 import os
 import sys
@@ -54,5 +58,24 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_c2():
+    out = {}
+    oracle.build()
+    p, v = oracle.init_state(16384, SEED)
+    idx = np.linspace(0, 16383, 64).astype(np.int64)
+    done = 0
+    for k in (100, 1000):
+        p, v = oracle.run(p, v, k - done)
+        done = k
+        out[f"n16384_k{k}_sample_idx"] = idx
+        out[f"n16384_k{k}_sample_pos"], out[f"n16384_k{k}_sample_vel"] = p[idx], v[idx]
+        out[f"n16384_k{k}_xor"] = np.array([np.bitwise_xor.reduce(p.view(np.uint32).ravel()),
+                                            np.bitwise_xor.reduce(v.view(np.uint32).ravel())], dtype=np.uint32)
+        print("k", k, "done", flush=True)
+    path = os.path.join(ROOT, "tests", "golden", "nbody_golden_c2.npz")
+    np.savez_compressed(path, seed=np.array([SEED]), **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    main_c2() if "--c2" in sys.argv[1:] else main()

@@ -198,6 +198,38 @@ def test_update_instance_boids_operator(nb, oracle):
         nb.update_instance_boids(inst, positions, np.zeros((n - 1, 3), np.float32), velocities, old_v)
 
 
+def test_update_instance_boids_zip_truncation_and_frames(nb, oracle):
+    """instances shorter than positions: only that many bodies move while the folds see everyone (main.rs:465-471);
+    velocities shorter than positions is where the reference indexes old_velocities out of bounds (main.rs:496)."""
+    n, m = 300, 40
+    pos, vel = cloud(oracle, n, seed=22)
+    p_ref, v_ref = oracle.boids_step_range(pos, vel, 0, m)
+    positions, velocities = pos.copy(), vel.copy()
+    inst = np.zeros((m, 4, 4), np.float32)
+    nb.update_instance_boids(inst, positions, np.zeros_like(pos), velocities, np.zeros_like(vel))
+    assert_bits_equal(positions[:m], p_ref)
+    assert_bits_equal(velocities[:m], v_ref)
+    assert_bits_equal(positions[m:], pos[m:])
+    assert_bits_equal(velocities[m:], vel[m:])
+    with pytest.raises(ValueError, match="out of bounds"):
+        nb.update_instance_boids(np.zeros((n, 4, 4), np.float32), positions, np.zeros_like(pos), velocities[:m].copy(),
+                                 np.zeros((m, 3), np.float32))
+    # frame after frame on the same Vecs, alternating with the n-body function (they share the cached context)
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n, 4, 4), np.float32)
+    p_ref, v_ref = pos, vel
+    for frame in range(4):
+        if frame % 2 == 0:
+            nb.update_instance_boids(inst, positions, old_p, velocities, old_v)
+            p_ref, v_ref = oracle.boids_run(p_ref, v_ref, 1)
+        else:
+            nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+            p_ref, v_ref = oracle.run(p_ref, v_ref, 1)
+        assert_bits_equal(positions, p_ref, f"frame {frame}")
+        assert_bits_equal(velocities, v_ref, f"frame {frame}")
+
+
 def test_boids_sharded_launch_equals_unsharded(nb, oracle):
     """What each rank of a multi-GPU job runs: index ranges of one step, positions AND velocities written per range."""
     import torch

@@ -160,6 +160,24 @@ def test_strict_config2_n16384_vs_oracle_and_golden(nb, oracle):
     assert_bits_equal(v, v_ref)
 
 
+def test_strict_config2_n16384_long_horizons_vs_golden(nb):
+    """BASELINE config 2 at the horizons SURVEY.md section 8d names: K = 100 and K = 1 000 (north_star: positions after
+    1 000 steps within 1e-4 -- here every bit of every body, through the XOR of all bit patterns)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden_c2.npz"))
+    pos, vel = nb.init_state(16384, int(g["seed"][0]))
+    with nb.Scene(pos, vel) as sc:
+        done = 0
+        for k in (100, 1000):
+            sc.step_n(k - done)
+            done = k
+            p, v = sc.state()
+            idx = g[f"n16384_k{k}_sample_idx"]
+            assert_bits_equal(p[idx], g[f"n16384_k{k}_sample_pos"], f"k={k} sampled positions")
+            assert_bits_equal(v[idx], g[f"n16384_k{k}_sample_vel"], f"k={k} sampled velocities")
+            assert np.bitwise_xor.reduce(bits(p).ravel()) == g[f"n16384_k{k}_xor"][0], f"k={k}: some position bit differs"
+            assert np.bitwise_xor.reduce(bits(v).ravel()) == g[f"n16384_k{k}_xor"][1], f"k={k}: some velocity bit differs"
+
+
 def test_strict_ieee_fallback_path_bit_exact(nb, oracle, lanes, monkeypatch):
     """The guarded '/' path (taken when coordinates leave the range where the shared-reciprocal ladder is
     proven exact) must give the same bits; force it for every tile."""
@@ -426,6 +444,54 @@ def test_update_instance_nbody_zip_truncation(nb, oracle):
     assert_bits_equal(velocities[m:], vel[m:])
 
 
+def test_update_instance_nbody_short_velocity_slice(nb, oracle):
+    """velocities shorter than positions: the zip stops there (main.rs:420-423); old_velocities is never read by the
+    n-body fold, so this is legal in the reference."""
+    n, m = 180, 33
+    pos, vel = state3d(oracle, n, seed=54)
+    p_ref, v_ref = oracle.step_range(pos, vel[:m], 0, m)
+    positions, velocities = pos.copy(), vel[:m].copy()
+    inst = np.full((n, 4, 4), 7, np.float32)
+    nb.update_instance_nbody(inst, positions, np.zeros_like(pos), velocities, np.zeros_like(velocities))
+    assert_bits_equal(positions[:m], p_ref)
+    assert_bits_equal(velocities, v_ref)
+    assert_bits_equal(positions[m:], pos[m:])
+    assert (inst[m:] == 7).all() and (inst[:m, 3, :3] == positions[:m]).all()
+
+
+def test_update_instance_nbody_called_every_frame(nb, oracle):
+    """The call-site shape of main.rs:925-931: the same Vecs every frame.  The library keeps its device context between
+    calls and must rebuild it when the body count or the constants change."""
+    from nenbody_amd import _lib
+
+    for n, frames, params in ((256, 4, None), (700, 2, None), (700, 2, nb.default_params(mode=nb.NB_MODE_STRICT, tile=256)),
+                              (256, 1, None)):
+        pos, vel = state3d(oracle, n, seed=60 + n)
+        positions, velocities = pos.copy(), vel.copy()
+        old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+        inst = np.zeros((n, 4, 4), np.float32)
+        for _ in range(frames):
+            nb.update_instance_nbody(inst, positions, old_p, velocities, old_v, params)
+        p_ref, v_ref = oracle.run(pos, vel, frames)
+        assert_bits_equal(positions, p_ref, f"n={n}")
+        assert_bits_equal(velocities, v_ref, f"n={n}")
+    # non-default constants reach the kernel
+    n = 128
+    pos, vel = state3d(oracle, n, seed=77)
+    prm = _lib.default_params()
+    prm.dt, prm.G, prm.bias = 0.05, 0.01, 1e-3
+    positions, velocities = pos.copy(), vel.copy()
+    nb.update_instance_nbody(np.zeros((n, 4, 4), np.float32), positions, np.zeros_like(pos), velocities, np.zeros_like(vel), prm)
+    p_ref, v_ref = oracle.run(pos, vel, 1, dt=0.05, g=0.01, bias=1e-3)
+    assert_bits_equal(positions, p_ref)
+    assert_bits_equal(velocities, v_ref)
+    nb.update_release()
+    nb.update_release()  # idempotent
+    nb.update_instance_nbody(np.zeros((n, 4, 4), np.float32), positions, np.zeros_like(pos), velocities, np.zeros_like(vel), prm)
+    p_ref, v_ref = oracle.run(p_ref, v_ref, 1, dt=0.05, g=0.01, bias=1e-3)
+    assert_bits_equal(positions, p_ref)
+
+
 def test_scene_step_refreshes_host_mirrors(nb, oracle):
     pos, vel = state3d(oracle, 100, seed=53)
     with nb.Scene.from_state(pos, vel) as sc:
@@ -505,6 +571,57 @@ def test_multirank_on_one_gpu_strict_equals_oracle(tmp_path, nb, oracle, world, 
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert_bits_equal(got["pos"], p_ref, f"rank {r} positions")
         assert_bits_equal(got["vel"], v_ref, f"rank {r} velocities")
+
+
+def _rccl_world_of_one(rank, port, n, k, out_dir):
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import nenbody_amd
+
+        pos, vel = nenbody_amd.init_state(n, 5)
+        sc = nenbody_amd.ShardedScene(pos, vel)
+        assert dist.get_backend() == "nccl"
+        for _ in range(k):
+            sc.step()
+            sc._all_gather_slots(sc.pos[sc.cur])  # the exchange bench.py --gpus N runs, here with one contributor
+            sc.step_boids()
+            sc._all_gather_slots(sc.velfull[sc.cur])
+        sc.sync()
+        np.savez(os.path.join(out_dir, "rccl.npz"), pos=sc.positions(), vel=sc.velocities())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_in_place_all_gather_world_of_one(tmp_path, nb, oracle):
+    """The RCCL leg itself (backend "nccl", send buffer = this rank's slot of the receive buffer) with the one rank this
+    box can give it: the collective must run on torch's stream between the kernels and leave the replica untouched."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n, k = 3000, 2
+    mp.spawn(_rccl_world_of_one, args=(port, n, k, str(tmp_path)), nprocs=1, join=True)
+    pos, vel = nb.init_state(n, 5)
+    for _ in range(k):
+        pos, vel = oracle.run(pos, vel, 1)
+        pos, vel = oracle.boids_run(pos, vel, 1)
+    got = np.load(os.path.join(str(tmp_path), "rccl.npz"))
+    assert_bits_equal(got["pos"], pos, "positions")
+    assert_bits_equal(got["vel"], vel, "velocities")
 
 
 # ---------------------------------------------------------------------------------------------------------

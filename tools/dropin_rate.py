@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the drop-in forms (diagnostic): Scene.step() refreshes the host mirrors every
-step (88 B/body over PCIe); update_instance_nbody() additionally uploads the state and creates/destroys a context per call."""
+step (88 B/body over PCIe); update_instance_nbody() / update_instance_boids() (one nb_update_instance_* call each) additionally
+upload the state every call; the device context is kept by the library between calls."""
 import os
 import sys
 import time
@@ -35,4 +36,10 @@ t0 = time.perf_counter()
 for _ in range(5):
     nb.update_instance_nbody(inst, p, op, v, ov)
 dt = (time.perf_counter() - t0) / 5
-print(f"update_instance_nbody (create + upload + step + download per call, STRICT): {dt * 1e3:.3f} ms/call = {n / dt:.3e} body-updates/s")
+print(f"update_instance_nbody (upload + step + download per call, STRICT): {dt * 1e3:.3f} ms/call = {n / dt:.3e} body-updates/s")
+nb.update_instance_boids(inst, p, op, v, ov)
+t0 = time.perf_counter()
+for _ in range(5):
+    nb.update_instance_boids(inst, p, op, v, ov)
+dt = (time.perf_counter() - t0) / 5
+print(f"update_instance_boids (upload + step + download per call): {dt * 1e3:.3f} ms/call = {n / dt:.3e} body-updates/s")
