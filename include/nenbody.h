@@ -217,6 +217,45 @@ int nb_launch_random_step(uint32_t first, uint32_t count, void *pos, void *vel, 
 int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream);
 int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void *stream);
 
+/* -- sharded scene: one process (or thread) per GPU ------------------------------------------------------ *
+ * The host side of the multi-GPU path in the library itself, for hosts that do not bring torch: rank r of `world`
+ * owns bodies [r*slot, r*slot + count) with slot = ceil(n / world) (trailing ranks may be short or empty) and a replica
+ * of all positions; one step is the local update followed by ONE exchange in which every rank contributes its slot of
+ * the new positions and receives the others' (`old_positions` of src/main.rs:415 is the replica).
+ * The boids controller exchanges velocities the same way (it reads every old velocity, src/main.rs:494-504).
+ * STRICT results do not depend on `world`.  The exchange is either RCCL (ncclAllGather in place, loaded with dlopen:
+ * NENBODY_RCCL, else the librccl.so.1 already in the process, else the system's) or a function the host supplies. */
+typedef struct nb_shard nb_shard;
+
+/* The exchange: `buf` is device memory of world*slot_bytes; this rank's slot (offset rank*slot_bytes) is ready on
+ * `stream` (a hipStream_t); on return (or: ordered on `stream`) every other slot must hold that rank's contribution.
+ * Return 0, or nonzero to fail the step with NB_ERR_STATE. */
+typedef int (*nb_gather_fn)(void *user, void *buf, size_t slot_bytes, int rank, int world, void *stream);
+
+#define NB_COMM_ID_BYTES 128
+/* A fresh RCCL unique id (ncclGetUniqueId): call on one rank, hand the NB_COMM_ID_BYTES to the others by any channel. */
+int nb_comm_id(void *id);
+
+/* Rank `rank` of `world` for n bodies on the current HIP device.  params == NULL -> defaults. */
+int nb_shard_create(uint32_t n, int rank, int world, const nb_params *params, nb_shard **out);
+void nb_shard_destroy(nb_shard *sh);
+/* Choose the exchange (required before stepping when world > 1).  nb_shard_use_rccl is collective over the ranks
+ * (ncclCommInitRank with the id from nb_comm_id). */
+int nb_shard_use_rccl(nb_shard *sh, const void *id);
+int nb_shard_use_gather(nb_shard *sh, nb_gather_fn fn, void *user);
+/* This rank's index range. */
+int nb_shard_range(const nb_shard *sh, uint32_t *first, uint32_t *count);
+/* Host -> device: ALL n positions and ALL n velocities (identical on every rank; the rank keeps its own velocities). */
+int nb_shard_upload(nb_shard *sh, const float *pos_xyz, const float *vel_xyz);
+/* k steps of update_instance_nbody / update_instance_boids, asynchronous; collective over the ranks. */
+int nb_shard_step(nb_shard *sh, uint32_t k);
+int nb_shard_step_boids(nb_shard *sh, uint32_t k, const nb_boids_params *params);
+/* Device -> host: all n positions (the replica), this rank's `count` velocities and model matrices.  Any may be NULL. */
+int nb_shard_download(nb_shard *sh, float *pos_xyz, float *vel_xyz_local, float *inst_16n_local);
+int nb_shard_sync(nb_shard *sh);
+/* Message of the last failure on `sh` (never NULL); creation failures are reported through nb_last_error(NULL). */
+const char *nb_shard_last_error(const nb_shard *sh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,62 @@ private:
     nb_ctx *ctx_ = nullptr;
 };
 
+// One rank's share of a scene on a multi-GPU host (one process or thread per GPU): nb_shard_* of nenbody.h.  Every rank
+// passes the same full state; the rank keeps its index range and a replica of all positions, and each step ends with
+// one exchange (RCCL when constructed with a comm id from Shard::comm_id(), else the host's nb_gather_fn).
+class Shard {
+public:
+    static std::array<char, NB_COMM_ID_BYTES> comm_id()
+    {
+        std::array<char, NB_COMM_ID_BYTES> id{};
+        check(nb_comm_id(id.data()), nullptr);
+        return id;
+    }
+    Shard(const std::vector<Vec3> &positions, const std::vector<Vec3> &velocities, int rank, int world, const nb_params &params,
+          const void *rccl_id = nullptr, nb_gather_fn gather = nullptr, void *gather_user = nullptr)
+    {
+        if (positions.empty() || positions.size() != velocities.size())
+            throw std::invalid_argument("positions and velocities must be non-empty and equally long");
+        check(nb_shard_create((uint32_t)positions.size(), rank, world, &params, &sh_), nullptr);
+        n_ = (uint32_t)positions.size();
+        try {
+            check_sh(nb_shard_range(sh_, &first_, &count_));
+            if (rccl_id) check_sh(nb_shard_use_rccl(sh_, rccl_id));
+            else if (gather) check_sh(nb_shard_use_gather(sh_, gather, gather_user));
+            check_sh(nb_shard_upload(sh_, positions[0].data(), velocities[0].data()));
+        } catch (...) {
+            nb_shard_destroy(sh_);
+            throw;
+        }
+    }
+    Shard(const Shard &) = delete;
+    Shard &operator=(const Shard &) = delete;
+    ~Shard() { nb_shard_destroy(sh_); }
+
+    uint32_t first() const { return first_; }
+    uint32_t count() const { return count_; }
+    void step(uint32_t k = 1) { check_sh(nb_shard_step(sh_, k)); }
+    void step_boids(uint32_t k = 1, const nb_boids_params *params = nullptr) { check_sh(nb_shard_step_boids(sh_, k, params)); }
+    void sync() { check_sh(nb_shard_sync(sh_)); }
+    // all n positions (the replica); this rank's velocities and model matrices
+    void download(std::vector<Vec3> &positions, std::vector<Vec3> &velocities_local, std::vector<Mat4> &instances_local)
+    {
+        positions.resize(n_);
+        velocities_local.resize(count_);
+        instances_local.resize(count_);
+        check_sh(nb_shard_download(sh_, positions[0].data(), count_ ? velocities_local[0].data() : nullptr,
+                                   count_ ? instances_local[0][0].data() : nullptr));
+    }
+
+private:
+    void check_sh(int rc)
+    {
+        if (rc != NB_OK) throw Error(rc, nb_shard_last_error(sh_));
+    }
+    nb_shard *sh_ = nullptr;
+    uint32_t n_ = 0, first_ = 0, count_ = 0;
+};
+
 // Drop-ins for the reference's free functions, src/main.rs:404-410 and 443-449: same five arguments, updated in place,
 // one FFI call each (nb_update_instance_nbody / nb_update_instance_boids keep the device context between calls).
 // A length mismatch is where copy_from_slice panics (src/main.rs:415-416): std::invalid_argument here.

@@ -62,6 +62,10 @@ class NbError(RuntimeError):
 
 
 # every symbol include/nenbody.h declares: name -> (restype, argtypes)
+NB_COMM_ID_BYTES = 128
+# nb_gather_fn: int (*)(void *user, void *buf, size_t slot_bytes, int rank, int world, void *stream)
+GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p)
+
 PROTOTYPES = {
     "nb_abi_version": (c_int, []),
     "nb_default_params": (None, [POINTER(NbParams)]),
@@ -96,6 +100,18 @@ PROTOTYPES = {
     "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
     "nb_launch_unpack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
+    "nb_comm_id": (c_int, [c_void_p]),
+    "nb_shard_create": (c_int, [c_uint32, c_int, c_int, POINTER(NbParams), POINTER(c_void_p)]),
+    "nb_shard_destroy": (None, [c_void_p]),
+    "nb_shard_use_rccl": (c_int, [c_void_p, c_void_p]),
+    "nb_shard_use_gather": (c_int, [c_void_p, GATHER_FN, c_void_p]),
+    "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
+    "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nb_shard_step": (c_int, [c_void_p, c_uint32]),
+    "nb_shard_step_boids": (c_int, [c_void_p, c_uint32, POINTER(NbBoidsParams)]),
+    "nb_shard_download": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_shard_sync": (c_int, [c_void_p]),
+    "nb_shard_last_error": (c_char_p, [c_void_p]),
 }
 
 _lib = None
@@ -121,6 +137,9 @@ def _preload_torch_hip_runtime() -> None:
         path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
         if os.path.exists(path):
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            rccl = os.path.join(os.path.dirname(path), "librccl.so")
+            if os.path.exists(rccl):  # nb_shard_use_rccl: the RCCL built against that runtime
+                os.environ.setdefault("NENBODY_RCCL", rccl)
     except Exception:  # pragma: no cover - best effort; the loader falls back to the system runtime
         pass
 

@@ -3,6 +3,7 @@
 // Host-side only: argument checking, launch-shape selection, device buffers of a context.  There is no
 // CPU implementation of the step in this library: without a HIP device every compute call fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -970,3 +971,5 @@ NB_EXPORT int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void
     }
     NB_LAUNCH_TLS(nbk::launch_unpack(count, (const float4 *)rec4, (float *)xyz, (hipStream_t)stream));
 }
+
+#include "nb_shard.inc"

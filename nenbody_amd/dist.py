@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import NbParams, check
 
-__all__ = ["partition", "ShardedScene", "HipBackend"]
+__all__ = ["partition", "ShardedScene", "HipBackend", "NativeShard", "comm_id"]
 
 
 def partition(n: int, world: int) -> List[Tuple[int, int]]:
@@ -215,3 +215,107 @@ class ShardedScene:
             mine = self.pos[self.cur][self.first:self.first + self.count]
             self.backend.instances(self.count, mine, self.vel, inst)
         return inst[: self.count].cpu().numpy().reshape(self.count, 4, 4).copy()
+
+
+def comm_id() -> bytes:
+    """A fresh RCCL unique id (``nb_comm_id``): make it on one rank, hand the bytes to the others by any channel."""
+    buf = ctypes.create_string_buffer(_lib.NB_COMM_ID_BYTES)
+    check(_lib.load().nb_comm_id(buf))
+    return buf.raw
+
+
+class NativeShard:
+    """One rank's share of a scene with the host side inside libnenbody_hip.so (``nb_shard_*``, include/nenbody.h).
+
+    The same decomposition as :class:`ShardedScene` -- index ranges, one exchange of positions per step (velocities too
+    for the boids controller) -- without torch: the exchange is RCCL (``comm_id`` = the bytes of :func:`comm_id`, made
+    on one rank) or ``gather``, a callable ``(buf_ptr, slot_bytes, rank, world, stream_ptr) -> None`` that completes the
+    all-gather of the device buffer at ``buf_ptr``.  This is what a Rust or C++ host binds; it is wrapped here so the
+    tests can drive it.
+    """
+
+    def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, rank: int = 0, world: int = 1,
+                 comm_id: Optional[bytes] = None, gather=None):
+        lib = _lib.load()
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        vel = np.ascontiguousarray(velocities, dtype=np.float32)
+        if pos.ndim != 2 or pos.shape[1] != 3 or pos.shape != vel.shape:
+            raise ValueError("positions and velocities must both have shape (n, 3)")
+        self.n, self.rank, self.world = len(pos), int(rank), int(world)
+        self.params = params if params is not None else _lib.default_params()
+        self._lib = lib
+        self._sh = ctypes.c_void_p()
+        check(lib.nb_shard_create(self.n, self.rank, self.world, ctypes.byref(self.params), ctypes.byref(self._sh)))
+        try:
+            first, count = ctypes.c_uint32(), ctypes.c_uint32()
+            self._check(lib.nb_shard_range(self._sh, ctypes.byref(first), ctypes.byref(count)))
+            self.first, self.count = first.value, count.value
+            self._gather_keepalive = None
+            if comm_id is not None:
+                if len(comm_id) != _lib.NB_COMM_ID_BYTES:
+                    raise ValueError(f"comm_id must be {_lib.NB_COMM_ID_BYTES} bytes")
+                self._check(lib.nb_shard_use_rccl(self._sh, ctypes.create_string_buffer(comm_id, len(comm_id))))
+            elif gather is not None:
+                def trampoline(_user, buf, slot_bytes, rank_, world_, stream):
+                    try:
+                        gather(buf, slot_bytes, rank_, world_, stream)
+                        return 0
+                    except Exception:  # pragma: no cover - reported as NB_ERR_STATE by the library
+                        import traceback
+
+                        traceback.print_exc()
+                        return 1
+
+                self._gather_keepalive = _lib.GATHER_FN(trampoline)
+                self._check(lib.nb_shard_use_gather(self._sh, self._gather_keepalive, None))
+            self._check(lib.nb_shard_upload(self._sh, pos.ctypes.data, vel.ctypes.data))
+        except Exception:
+            self.close()
+            raise
+
+    def _check(self, rc: int) -> None:
+        if rc != _lib.NB_OK:
+            raise _lib.NbError(rc, self._lib.nb_shard_last_error(self._sh).decode())
+
+    def step(self, k: int = 1) -> None:
+        self._check(self._lib.nb_shard_step(self._sh, int(k)))
+
+    def step_boids(self, k: int = 1, params=None) -> None:
+        self._check(self._lib.nb_shard_step_boids(self._sh, int(k), ctypes.byref(params) if params is not None else None))
+
+    def sync(self) -> None:
+        self._check(self._lib.nb_shard_sync(self._sh))
+
+    def positions(self) -> np.ndarray:
+        """All n positions (every rank holds the replica)."""
+        out = np.zeros((self.n, 3), np.float32)
+        self._check(self._lib.nb_shard_download(self._sh, out.ctypes.data, None, None))
+        return out
+
+    def local_velocities(self) -> np.ndarray:
+        out = np.zeros((self.count, 3), np.float32)
+        self._check(self._lib.nb_shard_download(self._sh, None, out.ctypes.data if self.count else None, None))
+        return out
+
+    def local_instances(self) -> np.ndarray:
+        out = np.zeros((self.count, 4, 4), np.float32)
+        self._check(self._lib.nb_shard_download(self._sh, None, None, out.ctypes.data if self.count else None))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_sh", None) is not None and self._sh:
+            self._lib.nb_shard_destroy(self._sh)
+            self._sh = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -48,6 +48,21 @@ int main(int argc, char **argv)
             } catch (const std::invalid_argument &) {
             }
         }
+        // the sharded host with a world of one (no exchange needed) must reproduce the same step
+        {
+            nenbody::Scene twin(n, prm, 1234);
+            nenbody::Shard shard(twin.positions, twin.velocities, 0, 1, prm);
+            shard.step(k + 1);
+            std::vector<nenbody::Vec3> sp, sv;
+            std::vector<nenbody::Mat4> si;
+            shard.download(sp, sv, si);
+            if (shard.first() != 0 || shard.count() != n ||
+                std::memcmp(sp.data(), scene.positions.data(), n * sizeof(nenbody::Vec3)) != 0 ||
+                std::memcmp(sv.data(), scene.velocities.data(), n * sizeof(nenbody::Vec3)) != 0) {
+                std::fprintf(stderr, "Shard (world of one) and Scene disagree\n");
+                return 7;
+            }
+        }
         FILE *f = std::fopen(argv[3], "wb");
         if (!f) return 4;
         std::fwrite(scene.positions.data(), sizeof(nenbody::Vec3), n, f);

@@ -168,3 +168,33 @@ def test_boids_defaults_and_launch_validation(nb):
     assert "tile" in _lib.last_error()
     assert lib.nb_launch_cameras(0, a, b, c, d, a, None) == _lib.NB_ERR_INVALID
     assert lib.nb_launch_random_step(0, 0, a, b, 1, 0, None) == _lib.NB_ERR_INVALID
+
+
+def test_shard_argument_contract_and_no_device(nb):
+    """nb_shard_*: arguments are validated before any device work; without a GPU nothing can be created."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    sh = ctypes.c_void_p()
+    for n, rank, world in ((0, 0, 1), (8, 0, 0), (8, 2, 2), (8, -1, 2)):
+        assert lib.nb_shard_create(n, rank, world, None, ctypes.byref(sh)) == _lib.NB_ERR_INVALID
+        assert not sh.value and b"rank" in lib.nb_last_error(None)
+    assert lib.nb_shard_create(8, 0, 1, None, None) == _lib.NB_ERR_INVALID
+    bad = _lib.default_params()
+    bad.mode = 9
+    assert lib.nb_shard_create(8, 0, 2, ctypes.byref(bad), ctypes.byref(sh)) == _lib.NB_ERR_INVALID
+    for fn, args in ((lib.nb_shard_step, (None, 1)), (lib.nb_shard_step_boids, (None, 1, None)), (lib.nb_shard_sync, (None,)),
+                     (lib.nb_shard_upload, (None, None, None)), (lib.nb_shard_download, (None, None, None, None)),
+                     (lib.nb_shard_range, (None, None, None)), (lib.nb_shard_use_rccl, (None, None)),
+                     (lib.nb_comm_id, (None,))):
+        assert fn(*args) == _lib.NB_ERR_INVALID
+    lib.nb_shard_destroy(None)
+    assert lib.nb_shard_last_error(None) is not None
+    if lib.nb_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    assert lib.nb_shard_create(8, 0, 2, None, ctypes.byref(sh)) == _lib.NB_ERR_NO_DEVICE and not sh.value
+    pos, vel = nb.init_state(8)
+    with pytest.raises(nb.NbError):
+        nb.NativeShard(pos, vel)
+    with pytest.raises(nb.NbError):   # no RCCL without a device either (NB_ERR_NO_DEVICE or NB_ERR_UNSUPPORTED if librccl is absent)
+        nb.comm_id()

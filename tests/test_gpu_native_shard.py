@@ -1,0 +1,173 @@
+"""GPU tests of the sharded host inside the library (nb_shard_*, include/nenbody.h): index ranges,
+one exchange per step, STRICT bits independent of the world size.  RCCL itself needs one GPU per rank, so on this
+one-GPU box it runs with a world of one; worlds of 2 and 3 run as processes sharing the GPU with a host-supplied
+exchange (gloo through the host), which drives every line of the stepping logic that RCCL would."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(got, ref, what=""):
+    g, r = bits(got), bits(ref)
+    assert g.shape == r.shape, f"{what}: shape {g.shape} vs {r.shape}"
+    assert (g == r).all(), f"{what}: {(g != r).sum()} of {g.size} words differ, first at {np.argwhere(g != r)[0]}"
+
+
+def state3d(oracle, n, seed):
+    pos, vel = oracle.init_state(n, seed)
+    rng = np.random.default_rng(seed)
+    pos[:, 2] = rng.uniform(-100, 100, n).astype(np.float32)
+    vel[:, 2] = rng.uniform(0, 0.1, n).astype(np.float32)
+    return (pos * np.float32(0.3)).astype(np.float32), vel
+
+
+def reference(oracle, pos, vel, schedule):
+    for what, k in schedule:
+        pos, vel = oracle.run(pos, vel, k) if what == "nbody" else oracle.boids_run(pos, vel, k)
+    return pos, vel
+
+
+SCHEDULE = (("nbody", 2), ("boids", 2), ("nbody", 1), ("boids", 1))
+
+
+def drive(sh, schedule):
+    for what, k in schedule:
+        sh.step(k) if what == "nbody" else sh.step_boids(k)
+    sh.sync()
+
+
+@pytest.mark.parametrize("n", [1, 700, 2049])
+def test_world_of_one_needs_no_exchange(nb, oracle, n):
+    pos, vel = state3d(oracle, n, seed=n)
+    with nb.NativeShard(pos, vel) as sh:
+        assert (sh.first, sh.count) == (0, n)
+        drive(sh, SCHEDULE)
+        p, v, inst = sh.positions(), sh.local_velocities(), sh.local_instances()
+    p_ref, v_ref = reference(oracle, pos, vel, SCHEDULE)
+    assert_bits_equal(p, p_ref, "positions")
+    assert_bits_equal(v, v_ref, "velocities")
+    assert np.allclose(inst, oracle.instances(p_ref, v_ref), rtol=0, atol=1e-6)
+
+
+def test_rccl_world_of_one(nb, oracle):
+    """ncclGetUniqueId -> ncclCommInitRank -> ncclAllGather in place between the kernels, on the library's stream."""
+    n = 1500
+    pos, vel = state3d(oracle, n, seed=3)
+    cid = nb.comm_id()
+    assert len(cid) == 128 and any(cid)
+    with nb.NativeShard(pos, vel, rank=0, world=1, comm_id=cid) as sh:
+        drive(sh, SCHEDULE)
+        p, v = sh.positions(), sh.local_velocities()
+    p_ref, v_ref = reference(oracle, pos, vel, SCHEDULE)
+    assert_bits_equal(p, p_ref, "positions")
+    assert_bits_equal(v, v_ref, "velocities")
+
+
+def test_a_world_above_one_refuses_to_step_without_an_exchange(nb, oracle):
+    from nenbody_amd import _lib
+
+    pos, vel = state3d(oracle, 100, seed=4)
+    with nb.NativeShard(pos, vel, rank=1, world=2) as sh:
+        assert (sh.first, sh.count) == (50, 50)
+        with pytest.raises(nb.NbError) as ei:
+            sh.step()
+        assert ei.value.status == _lib.NB_ERR_STATE and "nb_shard_use_rccl" in str(ei.value)
+
+
+def test_failing_host_exchange_fails_the_step(nb, oracle):
+    from nenbody_amd import _lib
+
+    def broken(buf, slot_bytes, rank, world, stream):
+        raise RuntimeError("link down")
+
+    pos, vel = state3d(oracle, 64, seed=5)
+    with nb.NativeShard(pos, vel, rank=0, world=2, gather=broken) as sh:
+        with pytest.raises(nb.NbError) as ei:
+            sh.step()
+        assert ei.value.status == _lib.NB_ERR_STATE
+
+
+# -- worlds of 2 and 3 as processes on the one GPU, exchange = gloo through the host ------------------------------------
+def _hip_runtime():
+    """The HIP runtime already in the process (nenbody_amd preloads it globally), for raw memcpy on device pointers."""
+    hip = ctypes.CDLL(None)
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemcpy.restype = ctypes.c_int
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.restype = ctypes.c_int
+    return hip
+
+
+def _rank_worker(rank, world, port, n, mode, out_dir):
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nenbody_amd
+        import oracle
+
+        nenbody_amd.load()   # brings the HIP runtime into the global symbol scope
+        hip = _hip_runtime()
+        calls = []
+
+        def gather(buf, slot_bytes, rank_, world_, stream):
+            assert (rank_, world_) == (rank, world)
+            assert hip.hipStreamSynchronize(stream) == 0          # this rank's slot is ready
+            mine = torch.empty(slot_bytes, dtype=torch.uint8)
+            assert hip.hipMemcpy(mine.data_ptr(), buf + rank * slot_bytes, slot_bytes, 2) == 0   # device -> host
+            full = torch.empty(world * slot_bytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(full, mine)
+            assert hip.hipMemcpy(buf, full.data_ptr(), world * slot_bytes, 1) == 0               # host -> device
+            calls.append(slot_bytes)
+
+        pos, vel = state3d(oracle, n, seed=n)
+        with nenbody_amd.NativeShard(pos, vel, nenbody_amd.default_params(mode=mode), rank=rank, world=world,
+                                     gather=gather) as sh:
+            drive(sh, SCHEDULE)
+            np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sh.positions(), vel=sh.local_velocities(),
+                     inst=sh.local_instances(), first=sh.first, count=sh.count, calls=len(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 3000), (3, 1000), (3, 2)])
+def test_worlds_of_two_and_three_equal_the_oracle(tmp_path, nb, oracle, world, n):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_STRICT, str(tmp_path)), nprocs=world, join=True)
+    pos, vel = state3d(oracle, n, seed=n)
+    p_ref, v_ref = reference(oracle, pos, vel, SCHEDULE)
+    inst_ref = oracle.instances(p_ref, v_ref)
+    covered = 0
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        first, count = int(got["first"]), int(got["count"])
+        assert (first, count) == nb.partition(n, world)[r]
+        assert_bits_equal(got["pos"], p_ref, f"rank {r} positions (replica)")
+        assert_bits_equal(got["vel"], v_ref[first:first + count], f"rank {r} velocities")
+        assert np.allclose(got["inst"], inst_ref[first:first + count], rtol=0, atol=1e-6)
+        # n-body: one exchange per step; boids: positions + velocities per step, + one rebuild of the velocity replica
+        # each time boids follows n-body steps
+        assert int(got["calls"]) == 3 + (1 + 2 * 2) + (1 + 2 * 1)
+        covered += count
+    assert covered == n
