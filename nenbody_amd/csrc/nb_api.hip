@@ -331,6 +331,8 @@ struct nb_ctx {
     float *stage = nullptr;   // 3n floats: stride-3 staging for upload/download
     float4 *inst = nullptr;   // 4n float4, allocated on first use
     float4 *cams = nullptr;   // 4n float4, allocated on first use (nb_cameras)
+    float *xfer = nullptr;    // 22n floats [matrices 16n | positions 3n | velocities 3n]: one-copy round trip of the drop-in calls
+    float *hxfer = nullptr;   // its pinned host twin
     void *scratch = nullptr;
     int cur = 0;
     bool uploaded = false;
@@ -404,6 +406,8 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->inst) (void)hipFree(ctx->inst);
     if (ctx->cams) (void)hipFree(ctx->cams);
+    if (ctx->xfer) (void)hipFree(ctx->xfer);
+    if (ctx->hxfer) (void)hipHostFree(ctx->hxfer);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -659,7 +663,7 @@ struct UpdateCache {
     std::mutex mu;
     nb_ctx *ctx = nullptr;
     nb_params p{};
-    std::vector<float> vel_full, pos_tmp, vel_tmp, inst_tmp;
+    std::vector<float> vel_full, tmp;
 };
 // never destroyed: a static destructor could run after the HIP runtime's own teardown
 UpdateCache &update_cache()
@@ -672,6 +676,38 @@ int update_fail(UpdateCache &uc, const char *who, int rc)
 {
     g_tls_error = std::string(who) + ": " + (uc.ctx ? uc.ctx->err : g_tls_error);
     return rc;
+}
+
+// upload + one step + download with ONE host<->device copy each way and one wait: the per-frame cost of the drop-in
+// calls at the reference's own sizes (entity_count 100 .. 2048) is all latency, so every separate copy and
+// synchronisation of nb_upload / nb_download shows.  pos / vel: n bodies each; outputs: the first `count` bodies.
+int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const float *pos, const float *vel, size_t count,
+                     float *pos_out, float *vel_out, float *inst_out)
+{
+    const size_t n = c->n, xyz = 3 * sizeof(float);
+    if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, n * 22 * sizeof(float)));
+    if (!c->hxfer) NB_HIP(c, hipHostMalloc((void **)&c->hxfer, n * 22 * sizeof(float), hipHostMallocDefault));
+    if (!c->inst) NB_HIP(c, hipMalloc((void **)&c->inst, n * 16 * sizeof(float)));
+    std::memcpy(c->hxfer, pos, n * xyz);
+    std::memcpy(c->hxfer + 3 * n, vel, n * xyz);
+    c->cur = 0;
+    NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, nbk::launch_pack(c->n, c->xfer, c->pos[0], c->stream));
+    NB_HIP(c, nbk::launch_pack(c->n, c->xfer + 3 * n, c->vel, c->stream));
+    c->uploaded = true;
+    c->steps = 0;
+    int rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
+    if (rc != NB_OK) return rc;
+    float *d_inst = c->xfer, *d_pos = c->xfer + 16 * n, *d_vel = c->xfer + 19 * n;
+    NB_HIP(c, nbk::launch_instances(c->n, c->pos[c->cur], c->vel, (float4 *)d_inst, c->stream));
+    NB_HIP(c, nbk::launch_unpack(c->n, c->pos[c->cur], d_pos, c->stream));
+    NB_HIP(c, nbk::launch_unpack(c->n, c->vel, d_vel, c->stream));
+    NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, n * 22 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    NB_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));
+    std::memcpy(pos_out, c->hxfer + 16 * n, count * xyz);
+    std::memcpy(vel_out, c->hxfer + 19 * n, count * xyz);
+    return NB_OK;
 }
 
 int update_common(const char *who, bool boids, float *inst, size_t n_inst, float *pos, size_t n_pos, float *opos, size_t n_opos,
@@ -721,7 +757,17 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
         std::memcpy(uc.vel_full.data(), ovel, n_vel * xyz);
         vel_src = uc.vel_full.data();
     }
-    int rc = nb_upload(uc.ctx, opos, vel_src);
+    // Small sets are all latency: one copy each way through pinned memory (41 us per call at N = 100, 87 us at 2 048,
+    // against 104 / 143 us with separate copies).  Large sets are all bandwidth: copy straight from and to the caller's
+    // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
+    constexpr uint32_t kRoundtripMax = 16384;
+    int rc;
+    if (n <= kRoundtripMax) {
+        rc = update_roundtrip(uc.ctx, boids, bp, opos, vel_src, count, pos, vel, inst);
+        if (rc != NB_OK) return update_fail(uc, who, rc);
+        return NB_OK;
+    }
+    rc = nb_upload(uc.ctx, opos, vel_src);
     if (rc == NB_OK) rc = boids ? nb_step_boids(uc.ctx, 1, bp) : nb_step(uc.ctx, 1);
     if (rc != NB_OK) return update_fail(uc, who, rc);
     if (count == n_pos) {  // the usual case: all three slices as long as the set
@@ -729,14 +775,13 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
-    uc.pos_tmp.resize(n_pos * 3);
-    uc.vel_tmp.resize(n_pos * 3);
-    uc.inst_tmp.resize(n_pos * 16);
-    rc = nb_download(uc.ctx, uc.pos_tmp.data(), uc.vel_tmp.data(), uc.inst_tmp.data());
+    uc.tmp.resize(n_pos * 22);
+    float *pos_tmp = uc.tmp.data(), *vel_tmp = pos_tmp + 3 * n_pos, *inst_tmp = pos_tmp + 6 * n_pos;
+    rc = nb_download(uc.ctx, pos_tmp, vel_tmp, inst_tmp);
     if (rc != NB_OK) return update_fail(uc, who, rc);
-    std::memcpy(pos, uc.pos_tmp.data(), count * xyz);
-    std::memcpy(vel, uc.vel_tmp.data(), count * xyz);
-    std::memcpy(inst, uc.inst_tmp.data(), count * 16 * sizeof(float));
+    std::memcpy(pos, pos_tmp, count * xyz);
+    std::memcpy(vel, vel_tmp, count * xyz);
+    std::memcpy(inst, inst_tmp, count * 16 * sizeof(float));
     return NB_OK;
 }
 }  // namespace
@@ -768,9 +813,7 @@ NB_EXPORT void nb_update_release(void)
     if (uc.ctx) nb_destroy(uc.ctx);
     uc.ctx = nullptr;
     uc.vel_full = std::vector<float>();
-    uc.pos_tmp = std::vector<float>();
-    uc.vel_tmp = std::vector<float>();
-    uc.inst_tmp = std::vector<float>();
+    uc.tmp = std::vector<float>();
 }
 
 NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair)

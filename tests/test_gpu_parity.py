@@ -430,9 +430,9 @@ def test_update_instance_nbody_matches_reference_semantics(nb, oracle):
     assert (inst[:, 3, :3] == positions).all()       # translation column is the new position, exactly
 
 
-def test_update_instance_nbody_zip_truncation(nb, oracle):
+@pytest.mark.parametrize("n,m", [(200, 50), (20000, 70)])   # both transfer paths of the drop-in call (small / large sets)
+def test_update_instance_nbody_zip_truncation(nb, oracle, n, m):
     """instances shorter than positions: only that many bodies move, the fold still sees everyone (main.rs:420-425)."""
-    n, m = 200, 50
     pos, vel = state3d(oracle, n, seed=52)
     p_ref, v_ref = oracle.step_range(pos, vel[:m], 0, m)
     positions, velocities = pos.copy(), vel.copy()
@@ -465,7 +465,7 @@ def test_update_instance_nbody_called_every_frame(nb, oracle):
     from nenbody_amd import _lib
 
     for n, frames, params in ((256, 4, None), (700, 2, None), (700, 2, nb.default_params(mode=nb.NB_MODE_STRICT, tile=256)),
-                              (256, 1, None)):
+                              (17000, 2, None), (256, 1, None)):
         pos, vel = state3d(oracle, n, seed=60 + n)
         positions, velocities = pos.copy(), vel.copy()
         old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
