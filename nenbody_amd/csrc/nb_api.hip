@@ -413,6 +413,18 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     delete ctx;
 }
 
+// Sets up to this size cross the bus as ONE pinned copy each way (they are all latency: every separate copy and wait
+// shows); larger sets are all bandwidth and copy straight from / to the caller's arrays.  Measured: tools/crossover.py.
+constexpr uint32_t kRoundtripMax = 16384;
+
+static int ensure_xfer(nb_ctx *c)
+{
+    const size_t bytes = (size_t)c->n * 22 * sizeof(float);
+    if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, bytes));
+    if (!c->hxfer) NB_HIP(c, hipHostMalloc((void **)&c->hxfer, bytes, hipHostMallocDefault));
+    return NB_OK;
+}
+
 static int create_impl(nb_ctx *c)
 {
     const size_t rec = (size_t)c->n * sizeof(float4);
@@ -478,6 +490,20 @@ NB_EXPORT int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz)
     }
     const size_t bytes = (size_t)ctx->n * 3 * sizeof(float);
     ctx->cur = 0;
+    if (ctx->n <= kRoundtripMax) {  // one pinned copy, no wait: the stream orders it before the first step
+        int rc = ensure_xfer(ctx);
+        if (rc != NB_OK) return rc;
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a download still reading hxfer must be done (it always is: downloads wait)
+        std::memcpy(ctx->hxfer, pos_xyz, bytes);
+        std::memcpy(ctx->hxfer + 3 * (size_t)ctx->n, vel_xyz, bytes);
+        NB_HIP(ctx, hipMemcpyAsync(ctx->xfer, ctx->hxfer, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
+        NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->xfer, ctx->pos[0], ctx->stream));
+        NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->xfer + 3 * (size_t)ctx->n, ctx->vel, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // hxfer / xfer are reused by the next call
+        ctx->uploaded = true;
+        ctx->steps = 0;
+        return NB_OK;
+    }
     NB_HIP(ctx, hipMemcpyAsync(ctx->stage, pos_xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
     NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->stage, ctx->pos[0], ctx->stream));
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // stage is reused; the host array is not retained
@@ -636,6 +662,21 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         return NB_ERR_STATE;
     }
     const size_t bytes = (size_t)ctx->n * 3 * sizeof(float);
+    if (ctx->n <= kRoundtripMax && (pos_xyz || vel_xyz || inst_16n)) {  // [matrices 16n | positions 3n | velocities 3n], one copy, one wait
+        int rc = ensure_xfer(ctx);
+        if (rc != NB_OK) return rc;
+        const size_t n = ctx->n;
+        if (inst_16n) NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, (float4 *)ctx->xfer, ctx->stream));
+        if (pos_xyz) NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->xfer + 16 * n, ctx->stream));
+        if (vel_xyz) NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->vel, ctx->xfer + 19 * n, ctx->stream));
+        const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
+        NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (inst_16n) std::memcpy(inst_16n, ctx->hxfer, n * 16 * sizeof(float));
+        if (pos_xyz) std::memcpy(pos_xyz, ctx->hxfer + 16 * n, bytes);
+        if (vel_xyz) std::memcpy(vel_xyz, ctx->hxfer + 19 * n, bytes);
+        return NB_OK;
+    }
     if (pos_xyz) {
         NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->stage, ctx->stream));
         NB_HIP(ctx, hipMemcpyAsync(pos_xyz, ctx->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -685,9 +726,8 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
                      float *pos_out, float *vel_out, float *inst_out)
 {
     const size_t n = c->n, xyz = 3 * sizeof(float);
-    if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, n * 22 * sizeof(float)));
-    if (!c->hxfer) NB_HIP(c, hipHostMalloc((void **)&c->hxfer, n * 22 * sizeof(float), hipHostMallocDefault));
-    if (!c->inst) NB_HIP(c, hipMalloc((void **)&c->inst, n * 16 * sizeof(float)));
+    int rc0 = ensure_xfer(c);
+    if (rc0 != NB_OK) return rc0;
     std::memcpy(c->hxfer, pos, n * xyz);
     std::memcpy(c->hxfer + 3 * n, vel, n * xyz);
     c->cur = 0;
@@ -760,7 +800,6 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     // Small sets are all latency: one copy each way through pinned memory (41 us per call at N = 100, 87 us at 2 048,
     // against 104 / 143 us with separate copies).  Large sets are all bandwidth: copy straight from and to the caller's
     // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
-    constexpr uint32_t kRoundtripMax = 16384;
     int rc;
     if (n <= kRoundtripMax) {
         rc = update_roundtrip(uc.ctx, boids, bp, opos, vel_src, count, pos, vel, inst);
