@@ -497,8 +497,7 @@ NB_EXPORT int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz)
         std::memcpy(ctx->hxfer, pos_xyz, bytes);
         std::memcpy(ctx->hxfer + 3 * (size_t)ctx->n, vel_xyz, bytes);
         NB_HIP(ctx, hipMemcpyAsync(ctx->xfer, ctx->hxfer, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
-        NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->xfer, ctx->pos[0], ctx->stream));
-        NB_HIP(ctx, nbk::launch_pack(ctx->n, ctx->xfer + 3 * (size_t)ctx->n, ctx->vel, ctx->stream));
+        NB_HIP(ctx, nbk::launch_import(ctx->n, ctx->xfer, ctx->xfer + 3 * (size_t)ctx->n, ctx->pos[0], ctx->vel, ctx->stream));
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // hxfer / xfer are reused by the next call
         ctx->uploaded = true;
         ctx->steps = 0;
@@ -666,9 +665,8 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         int rc = ensure_xfer(ctx);
         if (rc != NB_OK) return rc;
         const size_t n = ctx->n;
-        if (inst_16n) NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, (float4 *)ctx->xfer, ctx->stream));
-        if (pos_xyz) NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->xfer + 16 * n, ctx->stream));
-        if (vel_xyz) NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->vel, ctx->xfer + 19 * n, ctx->stream));
+        NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)ctx->xfer : nullptr,
+                                       pos_xyz ? ctx->xfer + 16 * n : nullptr, vel_xyz ? ctx->xfer + 19 * n : nullptr, ctx->stream));
         const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
         NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -722,26 +720,27 @@ int update_fail(UpdateCache &uc, const char *who, int rc)
 // upload + one step + download with ONE host<->device copy each way and one wait: the per-frame cost of the drop-in
 // calls at the reference's own sizes (entity_count 100 .. 2048) is all latency, so every separate copy and
 // synchronisation of nb_upload / nb_download shows.  pos / vel: n bodies each; outputs: the first `count` bodies.
+// upload + one step + download with ONE host<->device copy each way, one launch to unpack, one to pack, and one wait: the
+// per-frame cost of the drop-in calls at the reference's own sizes (entity_count 100 .. 2048) is all latency, so every
+// separate copy, launch and synchronisation shows.  (Replaying the five operations as a captured hipGraph was measured
+// too: 37 us per call at N = 100 against 30 us with plain launches, no difference at N = 2 048 -- not adopted.)
+// pos / vel: n bodies each; outputs: the first `count` bodies.
 int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const float *pos, const float *vel, size_t count,
                      float *pos_out, float *vel_out, float *inst_out)
 {
     const size_t n = c->n, xyz = 3 * sizeof(float);
-    int rc0 = ensure_xfer(c);
-    if (rc0 != NB_OK) return rc0;
+    int rc = ensure_xfer(c);
+    if (rc != NB_OK) return rc;
     std::memcpy(c->hxfer, pos, n * xyz);
     std::memcpy(c->hxfer + 3 * n, vel, n * xyz);
     c->cur = 0;
-    NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
-    NB_HIP(c, nbk::launch_pack(c->n, c->xfer, c->pos[0], c->stream));
-    NB_HIP(c, nbk::launch_pack(c->n, c->xfer + 3 * n, c->vel, c->stream));
     c->uploaded = true;
     c->steps = 0;
-    int rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
+    NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, nbk::launch_import(c->n, c->xfer, c->xfer + 3 * n, c->pos[0], c->vel, c->stream));
+    rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
     if (rc != NB_OK) return rc;
-    float *d_inst = c->xfer, *d_pos = c->xfer + 16 * n, *d_vel = c->xfer + 19 * n;
-    NB_HIP(c, nbk::launch_instances(c->n, c->pos[c->cur], c->vel, (float4 *)d_inst, c->stream));
-    NB_HIP(c, nbk::launch_unpack(c->n, c->pos[c->cur], d_pos, c->stream));
-    NB_HIP(c, nbk::launch_unpack(c->n, c->vel, d_vel, c->stream));
+    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)c->xfer, c->xfer + 16 * n, c->xfer + 19 * n, c->stream));
     NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, n * 22 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));

@@ -198,6 +198,25 @@ def test_update_instance_boids_operator(nb, oracle):
         nb.update_instance_boids(inst, positions, np.zeros((n - 1, 3), np.float32), velocities, old_v)
 
 
+def test_update_instance_boids_other_constants_every_other_frame(nb, oracle):
+    """The library keeps its device context between frames: constants that change from one frame to the next must take effect."""
+    n = 500
+    pos, vel = cloud(oracle, n, seed=23)
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n, 4, 4), np.float32)
+    p_ref, v_ref = pos, vel
+    for frame in range(5):
+        bp, obp = nb.default_boids_params(), oracle.boids_params()
+        if frame % 2:
+            bp.dt, bp.rule_2_distance, bp.rule_3_scale = 0.1, 9.0, 0.25
+            obp.dt, obp.rule_2_distance, obp.rule_3_scale = 0.1, 9.0, 0.25
+        nb.update_instance_boids(inst, positions, old_p, velocities, old_v, bp)
+        p_ref, v_ref = oracle.boids_run(p_ref, v_ref, 1, obp)
+        assert_bits_equal(positions, p_ref, f"frame {frame}")
+        assert_bits_equal(velocities, v_ref, f"frame {frame}")
+
+
 def test_update_instance_boids_zip_truncation_and_frames(nb, oracle):
     """instances shorter than positions: only that many bodies move while the folds see everyone (main.rs:465-471);
     velocities shorter than positions is where the reference indexes old_velocities out of bounds (main.rs:496)."""
