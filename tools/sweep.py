@@ -124,7 +124,7 @@ def main():
         # STRICT at the sizes given on the command line (default 131072), shape from the environment
         sizes = [int(x) for x in sys.argv[2:]] or [131072]
         for n in sizes:
-            run(n, nb.NB_MODE_STRICT, max(2, min(10, int(2e11 / (float(n) * n)))), {})
+            run(n, nb.NB_MODE_STRICT, max(2, min(2000, int(2e11 / (float(n) * n)))), {})
         return
     if what == "boidsshard":
         import torch
