@@ -178,6 +178,17 @@ void nb_update_release(void);
  * leave no guarded range (STRICT then always uses the IEEE divide). */
 int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair);
 
+/* Diagnostic, and the proof STRICT's division rests on.  With every intermediate normal (what the range guard ensures)
+ * the ladder commutes with scaling numerator and denominator by powers of two, so its result depends on the two 24-bit
+ * significands only.  nb_selftest_ladder compares it with the IEEE divide for `count` denominator significands starting
+ * at `first_significand` (both in [0, 2^23); d = 1.significand) against ALL 2^23 numerator significands, on the GPU;
+ * (0, 2^23) is the whole space, 7.0e13 pairs, under a minute on one MI355X.  *mismatches receives the number of differing
+ * quotients (expected 0); bad_pair, if non-NULL, one offending (n, d).  nb_selftest_rcp_scaling checks the one step that
+ * is not IEEE arithmetic: v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for every significand m and k in [k_lo, k_hi]
+ * (-125 <= k_lo <= k_hi <= 125); *violations receives the count (expected 0). */
+int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
+int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
+
 /* -- launch API: caller-owned device memory ------------------------------------------------------------ *
  * For hosts that own the device buffers and the exchange step themselves (one process per GPU, RCCL
  * all-gather of positions between steps).  Device layout: one 16-byte record per body,

@@ -89,6 +89,8 @@ PROTOTYPES = {
     "nb_update_instance_nbody": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbParams)]),
     "nb_update_instance_boids": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbBoidsParams)]),
     "nb_update_release": (None, []),
+    "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
+    "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),

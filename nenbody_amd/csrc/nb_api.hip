@@ -916,6 +916,68 @@ NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64
     return NB_OK;
 }
 
+NB_EXPORT int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair)
+{
+    if (!mismatches || count == 0 || first_significand >= (1u << 23) || count > (1u << 23) - first_significand) {
+        g_tls_error = "nb_selftest_ladder: need mismatches != NULL and a non-empty range of denominator significands inside [0, 2^23)";
+        return NB_ERR_INVALID;
+    }
+    int rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    uint32_t control = 0;  // NB_SELFTEST_CONTROL=1: the same steps on the UNREFINED reciprocal (control arm: must report mismatches)
+    env_u32("NB_SELFTEST_CONTROL", &control);
+    unsigned long long *d_bad = nullptr;
+    float *d_pair = nullptr;
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_pair, 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_pair, 0, 2 * sizeof(float));
+    const uint32_t slab = 1u << 13;  // 2^36 pairs per launch: a fraction of a second each, so no launch runs long
+    for (uint32_t done = 0; e == hipSuccess && done < count; done += slab) {
+        e = nbk::launch_ladder_exhaustive(first_significand + done, std::min(slab, count - done), control != 0, d_bad, d_pair, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    unsigned long long bad = 0;
+    float pair[2] = {0.f, 0.f};
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pair, d_pair, sizeof(pair), hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (d_pair) (void)hipFree(d_pair);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_selftest_ladder: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    *mismatches = bad;
+    if (bad_pair) {
+        bad_pair[0] = pair[0];
+        bad_pair[1] = pair[1];
+    }
+    return NB_OK;
+}
+
+NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
+{
+    if (!violations || k_lo > k_hi || k_lo < -125 || k_hi > 125) {
+        g_tls_error = "nb_selftest_rcp_scaling: need violations != NULL and -125 <= k_lo <= k_hi <= 125";
+        return NB_ERR_INVALID;
+    }
+    int rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    unsigned long long *d_bad = nullptr;
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = nbk::launch_rcp_scaling(k_lo, k_hi, d_bad, nullptr);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_selftest_rcp_scaling: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    *violations = bad;
+    return NB_OK;
+}
+
 // ---- launch API -----------------------------------------------------------------------------------------
 
 NB_EXPORT size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count)

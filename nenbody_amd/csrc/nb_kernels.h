@@ -44,6 +44,11 @@ hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs
 hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *vel, uint64_t seed, uint64_t step, hipStream_t s);
 hipError_t launch_divide_selftest(uint32_t blocks, uint64_t seed, uint32_t per_thread, int d_lo, int d_hi, int n_lo, int n_hi,
                                   unsigned long long *mismatches, float *first_bad, bool single_correction, hipStream_t s);
+// div_ladder against '/' for count_md denominator significands x all 2^23 numerator significands (control: unrefined reciprocal)
+hipError_t launch_ladder_exhaustive(uint32_t first_md, uint32_t count_md, bool control, unsigned long long *mismatches, float *first_bad,
+                                    hipStream_t s);
+// v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for all 2^23 significands m and k in [k_lo, k_hi]
+hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

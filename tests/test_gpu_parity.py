@@ -642,6 +642,46 @@ def test_strict_division_ladder_equals_ieee_divide(nb, g_, bias):
     assert bad.value == 0, f"{bad.value} mismatches, e.g. n={pair[0]!r} d={pair[1]!r}"
 
 
+def test_strict_division_ladder_is_exact_for_every_pair_of_significands(nb):
+    """The proof STRICT's arithmetic rests on: with normal intermediates the ladder's result depends on the two 24-bit
+    significands only, and here ALL 2^23 x 2^23 of them are compared with the IEEE divide (7.0e13 pairs; under a minute)."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    bad = ctypes.c_uint64(123)
+    pair = np.zeros(2, np.float32)
+    rc = lib.nb_selftest_ladder(0, 1 << 23, ctypes.byref(bad), pair.ctypes.data)
+    assert rc == 0, _lib.last_error()
+    assert bad.value == 0, f"{bad.value} mismatches, e.g. n={pair[0]!r} d={pair[1]!r}"
+
+
+def test_rcp_commutes_with_scaling_over_the_whole_normal_range(nb):
+    """The one step of the ladder that is not IEEE arithmetic: v_rcp_f32(m * 2^k) == v_rcp_f32(m) * 2^-k for every significand."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    bad = ctypes.c_uint64(123)
+    assert lib.nb_selftest_rcp_scaling(-125, 125, ctypes.byref(bad)) == 0, _lib.last_error()
+    assert bad.value == 0
+    assert lib.nb_selftest_rcp_scaling(-126, 0, ctypes.byref(bad)) == _lib.NB_ERR_INVALID
+
+
+def test_ladder_enumeration_can_fail(nb, monkeypatch):
+    """Control arm: the same steps on the UNREFINED reciprocal differ from '/' for some significands, and the run reports them."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    monkeypatch.setenv("NB_SELFTEST_CONTROL", "1")
+    bad = ctypes.c_uint64(0)
+    pair = np.zeros(2, np.float32)
+    # the last 2^16 denominator significands (mantissas near 2) hold most of the failures
+    assert lib.nb_selftest_ladder((1 << 23) - (1 << 16), 1 << 16, ctypes.byref(bad), pair.ctypes.data) == 0, _lib.last_error()
+    assert bad.value > 0 and 1.0 <= pair[0] < 2.0 and 1.0 <= pair[1] < 2.0
+    assert np.float32(pair[0]) / np.float32(pair[1]) != 0  # a usable counter-example came back
+    assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_ladder(0, 0, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
+
+
 def test_division_selftest_can_fail(nb, monkeypatch):
     """Control arm: comparing the uncorrected product n * (1/d) with the IEEE quotient must report mismatches (a few
     percent of the draws are one ulp off) -- i.e. the self-test is able to fail."""
