@@ -17,7 +17,7 @@ import sys
 def main(root):
     agg = collections.defaultdict(list)
     dur = collections.defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv"))):
+    for path in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"]
             if "nbk::" not in k:
