@@ -49,6 +49,7 @@ struct Plan {
     uint32_t unroll;                        // STRICT: pairs in flight per lane (2, 4 or 8)
     uint32_t lanes;                         // STRICT: lanes per body (1 = plain; 2..16 = j-parallel, same summation order)
     uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
+    uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
 };
 
 int floor_log2f(float x)
@@ -128,6 +129,8 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
     f = 0;
     pl.force_3d = (env_u32("NB_FORCE_3D", &f) && f) ? 2u : 0u;
+    f = 0;
+    pl.no_packed = (env_u32("NB_STRICT_NO_PACKED", &f) && f) ? 1u : 0u;
     // STRICT cannot split the fold over j (the sum is sequential), so a small shard would leave SIMDs idle:
     // below 65 536 bodies give each body S lanes until the shard supplies 2 waves per SIMD (256 CUs x 4 SIMDs x 2 =
     // 2048 waves).  The DPP adds of the j-parallel form cost about twice a plain add, so S = 1 stays ahead down to
@@ -179,6 +182,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.force_ieee = pl.force_ieee;
     a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
+    a.no_packed = pl.no_packed;
     hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);

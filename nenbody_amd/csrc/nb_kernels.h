@@ -17,6 +17,7 @@ struct StepArgs {
     uint32_t force_ieee;        // STRICT: 1 = always take the IEEE '/' path (parameters outside the proven range; tests)
     uint32_t force_3d;          // 2 (= kFlagNonPlanar) = never take the planar (z == 0) shortcut (tests, measurements)
     uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
+    uint32_t no_packed;         // STRICT: 1 = planar tiles take the component-packed fold instead of the j-packed one (tests, measurements)
 };
 
 // Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
