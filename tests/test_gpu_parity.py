@@ -40,7 +40,7 @@ def state3d(oracle, n, seed):
 # ---------------------------------------------------------------------------------------------------------
 # STRICT: bit-exact
 # ---------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, "1np", 2, 4, 8, 16, "pc8", "pc14"], ids=lambda s: f"lanes{s}")
+@pytest.fixture(params=[1, "1np", 2, 4, 8, 16, "pc8", "pc14", "pc14np"], ids=lambda s: f"lanes{s}")
 def lanes(request, monkeypatch):
     """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel) or "pc" = producer/consumer form; "1np" = one
     lane per body with planar tiles folded component-packed instead of j-packed (NB_STRICT_NO_PACKED=1).
@@ -51,7 +51,9 @@ def lanes(request, monkeypatch):
         monkeypatch.setenv("NB_STRICT_LANES", "1")
         monkeypatch.setenv("NB_STRICT_NO_PACKED", "1")
     elif str(request.param).startswith("pc"):
-        monkeypatch.setenv("NB_STRICT_PC", request.param[2:])   # producers per workgroup: 8 or 14
+        if request.param.endswith("np"):                         # component-packed producers instead of j-packed ones
+            monkeypatch.setenv("NB_STRICT_NO_PACKED", "1")
+        monkeypatch.setenv("NB_STRICT_PC", request.param[2:].replace("np", ""))   # producers per workgroup: 8 or 14
     else:
         monkeypatch.setenv("NB_STRICT_PC", "0")
         monkeypatch.setenv("NB_STRICT_LANES", str(request.param))
