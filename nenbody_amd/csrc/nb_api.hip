@@ -50,6 +50,8 @@ struct Plan {
     uint32_t lanes;                         // STRICT: lanes per body (1 = plain; 2..16 = j-parallel, same summation order)
     uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
     uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
+    uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
+    uint32_t n_total;                       // the set size the plan was made for
 };
 
 int floor_log2f(float x)
@@ -154,12 +156,17 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     env_u32("NB_STRICT_PC", &pl.pc);
     if (pl.pc == 1) pl.pc = 8;
     if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
+    pl.n_total = n_total;
+    pl.bc = 0;
+    env_u32("NB_STRICT_BC", &pl.bc);
+    pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     *out = pl;
     return NB_OK;
 }
 
 size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
+    if (pl.bc) return nbk::strict_bc_scratch_bytes(pl.n_total);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
 
@@ -182,8 +189,10 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.force_ieee = pl.force_ieee;
     a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
+    if (pl.bc) { uint32_t dbg = 0; env_u32("NB_BC_DEBUG", &dbg); a.j_chunk = dbg; }
     a.no_packed = pl.no_packed;
-    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, stream)
+                                                 : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
     if (e != hipSuccess) {

@@ -38,6 +38,9 @@ hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t pc, hipStrea
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_NOSLP_TU
 hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s);  // producer/consumer form: 64 bodies x (2 + producers) waves per workgroup
+// block-chain form for small shards: quotients stay in registers, running sums pass from wave to wave; needs scratch
+hipError_t launch_strict_bc(const StepArgs &a, void *scratch, hipStream_t s);
+size_t strict_bc_scratch_bytes(uint32_t n_total);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
 hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,

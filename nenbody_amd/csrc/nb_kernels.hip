@@ -28,6 +28,7 @@
 // that lose from SLP packing.  The kernels live in per-topic includes:
 //   nb_nbody_strict.inc  STRICT arithmetic + step_strict_kernel<TJ,U,S>  (S = 1 here; S > 1 "j-parallel" in the SLP-off unit)
 //   nb_nbody_pc.inc      STRICT producer/consumer kernel                  (this unit)
+//   nb_nbody_bc.inc      STRICT block-chain kernel for small shards        (this unit)
 //   nb_nbody_fast.inc    FAST kernel + fixed-order combine                (this unit)
 //   nb_aux.inc           model matrices, cameras, random walk, self-test  (this unit)
 //   nb_boids.inc         boids controller, one-lane and producer/consumer (SLP-off unit)
@@ -51,6 +52,7 @@ static constexpr int kWaves = kBlock / 64;
 #include "nb_boids.inc"
 #else
 #include "nb_nbody_pc.inc"
+#include "nb_nbody_bc.inc"
 #include "nb_nbody_fast.inc"
 #include "nb_aux.inc"
 #endif

@@ -40,13 +40,15 @@ def state3d(oracle, n, seed):
 # ---------------------------------------------------------------------------------------------------------
 # STRICT: bit-exact
 # ---------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, "1np", 2, 4, 8, 16, "pc8", "pc14", "pc14np"], ids=lambda s: f"lanes{s}")
+@pytest.fixture(params=[1, "1np", 2, 4, 8, 16, "pc8", "pc14", "pc14np", "bc"], ids=lambda s: f"lanes{s}")
 def lanes(request, monkeypatch):
     """STRICT launch shape: lanes per body (1 = plain, >1 = j-parallel) or "pc" = producer/consumer form; "1np" = one
     lane per body with planar tiles folded component-packed instead of j-packed (NB_STRICT_NO_PACKED=1).
     All of them keep the reference's summation order.  By default the library picks one from the shard size;
     the tests pin every value."""
-    if request.param == "1np":
+    if request.param == "bc":                                    # block-chain form (nb_nbody_bc.inc)
+        monkeypatch.setenv("NB_STRICT_BC", "1")
+    elif request.param == "1np":
         monkeypatch.setenv("NB_STRICT_PC", "0")
         monkeypatch.setenv("NB_STRICT_LANES", "1")
         monkeypatch.setenv("NB_STRICT_NO_PACKED", "1")

@@ -196,19 +196,21 @@ def main():
         for f3d in (0, 1):
             for world in (1, 2, 4, 8):
                 count = n_total // world
-                for pc in (0, 8, 14):
-                    env = {"NB_STRICT_PC": pc, "NB_FORCE_3D": f3d}
+                for pc in (0, 8, 14, "bc"):
+                    env = {"NB_STRICT_PC": 14 if pc == "bc" else pc, "NB_STRICT_BC": 1 if pc == "bc" else 0, "NB_FORCE_3D": f3d}
                     for k, v in env.items():
                         os.environ[k] = str(v)
                     params = nb.default_params(mode=nb.NB_MODE_STRICT)
                     v4 = torch.zeros((count, 4), device=dev)
+                    sb = be.scratch_bytes(params, n_total, count)
+                    scratch = torch.empty((sb,), dtype=torch.uint8, device=dev) if sb else None
                     for _ in range(2):
-                        be.step(params, n_total, 0, count, cur, nxt, v4, None)
+                        be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
                     torch.cuda.synchronize()
                     reps = 4
                     t0 = time.perf_counter()
                     for _ in range(reps):
-                        be.step(params, n_total, 0, count, cur, nxt, v4, None)
+                        be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / reps
                     print(f"3d={f3d} world={world} count={count:7d} pc={pc} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
