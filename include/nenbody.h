@@ -195,7 +195,8 @@ int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
  * float4 (x, y, z, 0) for positions and (vx, vy, vz, 0) for velocities.
  * `stream` is a hipStream_t (NULL = the default stream).  All launches are asynchronous.                 */
 
-/* Bytes of device scratch nb_launch_step needs for this shape (may be 0). */
+/* Bytes of device scratch nb_launch_step needs for this shape (may be 0): FAST with a split j range keeps partial sums
+ * there, STRICT below 65 536 bodies per rank the x / y / z planes of the position set (12 B per body of the WHOLE set). */
 size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count);
 
 /* One step for bodies [first, first+count) of a set of n_total:

@@ -101,6 +101,9 @@ def test_scratch_bytes_host_arithmetic(nb):
     lib = _lib.load()
     strict = nb.default_params()
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 0   # STRICT never splits the fold
+    # ... but a small shard of a big set runs the block-chain form, which keeps x / y / z planes of the whole set (+ flags)
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 256 + 3 * 4 * 131072
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 1000, 1000) == 0          # small sets: producer/consumer, no scratch
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
     b = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
     assert b % (16384 * 16) == 0 and 2 <= b // (16384 * 16) <= 64
