@@ -156,13 +156,14 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     env_u32("NB_STRICT_PC", &pl.pc);
     if (pl.pc == 1) pl.pc = 8;
     if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
-    // Below 65 536 bodies per rank the block-chain form (nb_nbody_bc.inc) is the default: 16 384 bodies against 131 072:
-    // 0.92 ms (producer/consumer 1.15), 32 768: 1.80 (2.28), 65 536: 3.55 (one lane per body 3.52).  It needs scratch
-    // memory (nb_scratch_bytes).  Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns it off; NB_STRICT_BC=0/1 decides outright.
+    // Up to 65 536 bodies per rank the block-chain form (nb_nbody_bc.inc) is the default.  Against all 131 072 bodies:
+    // 16 384 bodies 0.85 ms (producer/consumer 1.15), 32 768: 1.67 (2.28), 65 536: 3.30 (one lane per body 3.52); the whole
+    // set: 6.57 against 6.19 for one lane per body, which therefore keeps everything above.  It needs scratch memory
+    // (nb_scratch_bytes).  Sets below 4 096 bodies stay with producer/consumer: there the two extra launches cost more
+    // than the form gains.  Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns it off; NB_STRICT_BC=0/1 decides outright.
     pl.n_total = n_total;
     uint32_t named = 0;
-    // (sets below 4 096 bodies stay with producer/consumer: there the two extra launches cost more than the form gains)
-    pl.bc = (count < 65536u && n_total >= 4096u && !env_u32("NB_STRICT_PC", &named) && !env_u32("NB_STRICT_LANES", &named)) ? 1u : 0u;
+    pl.bc = (count <= 65536u && n_total >= 4096u && !env_u32("NB_STRICT_PC", &named) && !env_u32("NB_STRICT_LANES", &named)) ? 1u : 0u;
     env_u32("NB_STRICT_BC", &pl.bc);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     *out = pl;
