@@ -82,8 +82,8 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel):
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count else 0.0
     if mode == nb.NB_MODE_FAST:
         kernel = "step_fast_kernel"
-    else:  # nb_api.hip:make_plan: one lane per body from 65 536 bodies per rank, producer/consumer form below
-        kernel = "step_strict_kernel" if sc.count >= 65536 else "step_strict_pc_kernel"
+    else:  # nb_api.hip:make_plan: one lane per body above 65 536 bodies per rank, block chain up to there (tiny sets: producer/consumer)
+        kernel = "step_strict_kernel" if sc.count > 65536 else ("step_strict_bc_kernel" if sc.n >= 4096 else "step_strict_pc_kernel")
     return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "kernel": kernel}
 
 
