@@ -14,10 +14,12 @@
 //     no bank conflict), so each wave-instruction evaluates 64 pairs.
 //   - the work is fp32 VALU (no MFMA: pairwise math, not a contraction); HBM traffic is 48 B per
 //     body per step against 18*N flop per body, so the kernel is VALU-issue bound.
-//   - STRICT: the reference's exact binary32 operation order.  The three divides by the same
-//     denominator share one v_rcp_f32 + Newton step and then run the same FMA correction ladder the
-//     compiler's IEEE divide expands to (see div3_shared below); a per-tile range guard falls back to
-//     the plain IEEE '/' where the unscaled ladder would not be exact.  Result: bit-identical.
+//   - STRICT: the reference's exact binary32 operation order.  The divides by the same denominator share one
+//     v_rcp_f32 + Newton step and take ONE FMA correction step each (div_ladder): the compiler's IEEE divide takes two,
+//     and an enumeration of all 2^23 x 2^23 significand pairs shows the second never changes the result here; a range
+//     guard falls back to the plain IEEE '/' where the unscaled ladder is not covered by that proof.  The fold is packed
+//     across consecutive j's (pair2_strict), not across components.  Result: bit-identical.  Shards too small to fill
+//     the chip with one lane per body run the block-chain kernel (nb_nbody_bc.inc).
 //   - FAST: FMA chain for r^2, v_rcp_f32 for the divide, G hoisted, IB bodies per thread to amortise
 //     the LDS reads, j range optionally split over blockIdx.y with a fixed-order combine.
 //
