@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0            # same guide: HBM3E ~8 TB/s
 BYTES_PER_BODY_STEP = 64          # algorithmic HBM bytes: 16-B position + 16-B velocity record, read and written once
 
 
@@ -135,17 +136,23 @@ def main():
         steps_per_s = args.steps / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
         achieved = FLOP_PER_INTERACTION * r["count"] * r["n"] / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        traffic = measured_traffic(r["kernel"], r["n"], r["count"])
+        roof = {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                "bound_note": "fp32 vector ALU (SURVEY.md 8d): an all-pairs fp32 fold is neither HBM- nor MFMA-bound; see 'hbm'",
+                "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
+                "kernel": r["kernel"],
+                "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"]}
+        if traffic is not None and kernel_s > 0:  # how far from the HBM roofline the same launch is
+            gbps = traffic / kernel_s / 1e9
+            roof["hbm"] = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}
         return {
             "body_updates_per_s": n * steps_per_s,
             "interactions_per_s": float(n) * n * steps_per_s,
             "ms_per_step": 1e3 / steps_per_s,
             "kernel_ms": r["kernel_ms"],
-            "roofline": {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "traffic": measured_traffic(r["kernel"], r["n"], r["count"]), "traffic_unit": "bytes/launch (HBM, PMC)",
-                         "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
-                         "kernel": r["kernel"],
-                         "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"]},
+            "roofline": roof,
         }
 
     s = summarise(res)
