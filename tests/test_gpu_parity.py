@@ -474,7 +474,7 @@ def test_update_instance_nbody_called_every_frame(nb, oracle):
     from nenbody_amd import _lib
 
     for n, frames, params in ((256, 4, None), (700, 2, None), (700, 2, nb.default_params(mode=nb.NB_MODE_STRICT, tile=256)),
-                              (17000, 2, None), (256, 1, None)):
+                              (5000, 2, None), (17000, 2, None), (256, 1, None)):   # 5 000: block-chain kernel + one-copy round trip
         pos, vel = state3d(oracle, n, seed=60 + n)
         positions, velocities = pos.copy(), vel.copy()
         old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
