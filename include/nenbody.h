@@ -49,8 +49,9 @@ typedef enum nb_mode {
     /* Bit-identical to the reference's binary32 arithmetic: sequential j = 0..N-1 per body, no FMA
      * contraction, correctly rounded (vec*G)/dist per component.  The parity path. */
     NB_MODE_STRICT = 0,
-    /* Same law, reassociated for speed: r2 by FMA chain, v_rcp_f32 instead of the divide, G hoisted out
-     * of the sum, j range may be split and partial sums combined in a fixed (deterministic) order.
+    /* Same law, reassociated for speed: r2 by FMA chain, v_rcp_f32 instead of the divide (one reciprocal shared by two
+     * pairs where their product cannot leave the normal range), G hoisted out of the sum, j range may be split and
+     * partial sums combined in a fixed (deterministic) order.
      * Per-step relative force error ~1e-6; NOT bit-identical to the reference. */
     NB_MODE_FAST = 1
 } nb_mode;

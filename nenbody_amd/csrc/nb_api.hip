@@ -86,7 +86,9 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     pl.slices = 1;
     pl.j_chunk = n_total;
     if (p.mode == NB_MODE_FAST) {
-        pl.ib = (count >= 65536u) ? 4u : (count >= 32768u) ? 2u : 1u;
+        // bodies per thread; two or four also let the thread's pairs share reciprocals (measured against all 131 072 bodies:
+        // 131 072 / 65 536 / 32 768 bodies: 4 is fastest; 16 384: 2 -- 0.361 ms against 0.373 (1) and 0.375 (4))
+        pl.ib = (count >= 32768u) ? 4u : (count >= 16384u) ? 2u : 1u;  // (standalone sets of 8 192: 1 is fastest)
         env_u32("NB_FAST_IB", &pl.ib);
         if (pl.ib != 1 && pl.ib != 2 && pl.ib != 4) pl.ib = 1;
         const uint32_t blocks = (count + 256u * pl.ib - 1u) / (256u * pl.ib);
@@ -129,6 +131,13 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     }
     uint32_t f = 0;
     if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
+    if (p.mode == NB_MODE_FAST) {
+        // FAST reuses the field: 1 = never share a reciprocal between two pairs (the product of two r^2 must stay normal:
+        // bias in [2^-60, 2^60]; coordinates are checked per tile on the device).  NB_FAST_NO_SHARE=1: tests, measurements.
+        const bool bias_ok = std::isfinite(p.bias) && p.bias >= 0x1p-60f && p.bias <= 0x1p60f;
+        f = 0;
+        pl.force_ieee = (!bias_ok || (env_u32("NB_FAST_NO_SHARE", &f) && f)) ? 1u : 0u;
+    }
     f = 0;
     pl.force_3d = (env_u32("NB_FORCE_3D", &f) && f) ? 2u : 0u;
     f = 0;

@@ -409,6 +409,51 @@ def test_fast_every_launch_shape(nb, oracle, monkeypatch, ib, slices, tile):
     assert np.abs(p - p_ref).max() <= 1e-5
 
 
+def test_fast_shared_reciprocal_guard(nb, oracle, monkeypatch):
+    """FAST takes two reciprocals from one v_rcp_f32 (1/a = b * rcp(a*b)) where the product cannot leave binary32's normal
+    range.  Huge coordinates, and a bias outside [2^-60, 2^60], must fall back to one reciprocal per pair: same bits as with
+    sharing switched off (unguarded, the product of two r^2 ~ 1e19 overflows and both pairs silently contribute 0)."""
+    n = 3000
+    pos, vel = state3d(oracle, n, seed=91)
+    pos[17] = [3.0e9, -2.5e9, 1.0e9]          # |c| >= 2^28: r^2 ~ 1e19, the product of two of them overflows
+    pos[1500] = [-4.0e9, 1.0, 7.0e9]
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+
+    def run(no_share):
+        monkeypatch.setenv("NB_FAST_NO_SHARE", "1" if no_share else "0")
+        with nb.Scene(pos, vel, fast) as sc:
+            sc.step_n(1)
+            return sc.state()
+
+    p0, v0 = run(True)
+    p1, v1 = run(False)
+    assert np.isfinite(p0).all() and np.isfinite(v0).all()
+    assert_bits_equal(p1, p0, "tiles with huge coordinates must take the unshared form")
+    assert_bits_equal(v1, v0, "tiles with huge coordinates must take the unshared form (velocities)")
+    # a bias the product form cannot take: the host switches sharing off, so both settings give the same bits
+    tiny = nb.default_params(mode=nb.NB_MODE_FAST)
+    tiny.bias = 1e-30
+    pos2, vel2 = state3d(oracle, 2000, seed=92)
+    outs = []
+    for no_share in ("1", "0"):
+        monkeypatch.setenv("NB_FAST_NO_SHARE", no_share)
+        with nb.Scene(pos2, vel2, tiny) as sc:
+            sc.step_n(2)
+            outs.append(sc.state())
+    assert_bits_equal(outs[0][0], outs[1][0], "bias below 2^-60")
+    # and on ordinary data the two forms agree to a few ulp of the force
+    monkeypatch.setenv("NB_FAST_NO_SHARE", "1")
+    with nb.Scene(pos2, vel2, fast) as sc:
+        sc.step_n(1)
+        pa, va = sc.state()
+    monkeypatch.setenv("NB_FAST_NO_SHARE", "0")
+    with nb.Scene(pos2, vel2, fast) as sc:
+        sc.step_n(1)
+        pb, vb = sc.state()
+    dv = np.abs(va - vb).max()
+    assert dv <= 1e-6 * np.abs(va - vel2).max() + 1e-12, dv
+
+
 def test_fast_is_deterministic(nb, oracle, monkeypatch):
     monkeypatch.setenv("NB_FAST_SLICES", "8")
     pos, vel = state3d(oracle, 4096, seed=41)
