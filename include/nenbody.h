@@ -158,8 +158,9 @@ uint64_t nb_steps_done(const nb_ctx *ctx);
  *     unequal lengths are NB_ERR_INVALID, where copy_from_slice panics;
  *   - instances.zip(positions).zip(velocities) stops at the shortest (main.rs:420-423, 465-469): only that many
  *     bodies are written, while the folds still run over all of old_positions;
- *   - boids reads old_velocities[i] for every i < len(old_positions) (main.rs:494-504): a shorter velocity slice
- *     is NB_ERR_INVALID, where the reference indexes out of bounds and panics.
+ *   - boids folds rule 1 and rule 2 over old_positions.iter() (main.rs:471, 482) and rule 3 over old_velocities.iter()
+ *     (main.rs:494): each fold has its own slice's length, nothing is indexed by the other's, so positions and
+ *     velocities of different lengths are served as the reference serves them (the zip bounds which bodies move).
  * One upload, one step, one download per call.  The device context lives inside the library between calls and is
  * rebuilt when the body count or the constants change; calls are serialised by an internal lock.
  * params == NULL -> the reference constants. */
@@ -189,6 +190,13 @@ int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, u
  * (-125 <= k_lo <= k_hi <= 125); *violations receives the count (expected 0). */
 int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
 int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
+
+/* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
+ * NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
+ * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_SHARD_RCCL_SOLO) are read ONCE per process, at first use; no launch
+ * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
+ * and shards keep the launch shape chosen when they were created. */
+int nb_debug_reload_env(void);
 
 /* -- launch API: caller-owned device memory ------------------------------------------------------------ *
  * For hosts that own the device buffers and the exchange step themselves (one process per GPU, RCCL
@@ -225,6 +233,12 @@ int nb_launch_cameras(uint32_t count, const void *eyes, const void *dirs, const 
 
 /* One random-walk step (main.rs:381-402) in place for `count` bodies whose global indices start at `first`. */
 int nb_launch_random_step(uint32_t first, uint32_t count, void *pos, void *vel, uint64_t seed, uint64_t step, void *stream);
+
+/* Waits for `stream` and reports a failure a launch-API kernel recorded on the current device since the last call:
+ * NB_ERR_STATE when a STRICT block-chain workgroup gave up waiting for its turn (its outputs were written as NaN), NB_OK
+ * otherwise.  The context and shard objects make the same check themselves in nb_sync / nb_download / nb_shard_sync /
+ * nb_shard_download; a host that drives nb_launch_step directly calls this wherever it waits for the device. */
+int nb_launch_status(void *stream);
 
 /* Stride-3 <-> 16-byte record conversion on the device. */
 int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream);

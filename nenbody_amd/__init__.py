@@ -9,6 +9,14 @@ from ._lib import (NB_MODE_FAST, NB_MODE_STRICT, NbBoidsParams, NbError, NbParam
 from .scene import Scene, init_state, update_instance_boids, update_instance_nbody, update_release  # noqa: F401
 from .dist import NativeShard, ShardedScene, comm_id, partition  # noqa: F401
 
-__all__ = ["Scene", "ShardedScene", "NativeShard", "comm_id", "partition", "init_state", "update_instance_nbody", "update_instance_boids", "update_release",
+
+
+def reload_env() -> None:
+    """Have the library read its NB_* diagnostic overrides again (they are read once per process; tools that change
+    os.environ between runs call this: ``nb_debug_reload_env``)."""
+    load().nb_debug_reload_env()
+
+
+__all__ = ["reload_env", "Scene", "ShardedScene", "NativeShard", "comm_id", "partition", "init_state", "update_instance_nbody", "update_instance_boids", "update_release",
            "default_params", "default_boids_params", "load", "NbParams", "NbBoidsParams", "NbError", "NB_MODE_STRICT",
            "NB_MODE_FAST"]

@@ -99,6 +99,8 @@ PROTOTYPES = {
         c_int,
         [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "nb_launch_status": (c_int, [c_void_p]),
+    "nb_debug_reload_env": (c_int, []),
     "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
     "nb_launch_unpack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),

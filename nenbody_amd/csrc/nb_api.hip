@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -28,12 +29,71 @@ thread_local std::string g_tls_error = "";
 constexpr uint32_t kTargetWaves = 16384;
 constexpr uint32_t kMaxSlices = 64;
 
-int env_u32(const char *name, uint32_t *out)
+// ---- diagnostic overrides -----------------------------------------------------------------------------------
+// The parity tests pin every kernel form and the sweeps in tools/ time them; both do it through NB_* environment
+// variables.  They are read ONCE, on first use (and again only by nb_debug_reload_env()): no launch path calls getenv.
+struct Knob {
+    bool set = false;
+    uint32_t v = 0;
+    // the override if present, else the default
+    uint32_t or_else(uint32_t dflt) const { return set ? v : dflt; }
+    bool on() const { return set && v != 0; }
+};
+struct DebugOverrides {
+    Knob tile, fast_ib, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
+        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo;
+    uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
+};
+
+Knob read_knob(const char *name)
 {
+    Knob k;
     const char *s = std::getenv(name);
-    if (!s || !*s) return 0;
-    *out = (uint32_t)std::strtoul(s, nullptr, 10);
-    return 1;
+    if (s && *s) {
+        k.set = true;
+        k.v = (uint32_t)std::strtoul(s, nullptr, 10);
+    }
+    return k;
+}
+
+std::atomic<const DebugOverrides *> g_overrides{nullptr};
+std::mutex g_overrides_mu;
+
+const DebugOverrides *parse_overrides(uint32_t generation)
+{
+    DebugOverrides *d = new DebugOverrides();  // never freed: a handful per process at most (one, outside the test suite)
+    d->tile = read_knob("NB_TILE");
+    d->fast_ib = read_knob("NB_FAST_IB");
+    d->fast_slices = read_knob("NB_FAST_SLICES");
+    d->fast_no_share = read_knob("NB_FAST_NO_SHARE");
+    d->strict_force_ieee = read_knob("NB_STRICT_FORCE_IEEE");
+    d->force_3d = read_knob("NB_FORCE_3D");
+    d->strict_no_packed = read_knob("NB_STRICT_NO_PACKED");
+    d->strict_lanes = read_knob("NB_STRICT_LANES");
+    d->strict_unroll = read_knob("NB_STRICT_UNROLL");
+    d->strict_pc = read_knob("NB_STRICT_PC");
+    d->strict_bc = read_knob("NB_STRICT_BC");
+    d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
+    d->boids_pc = read_knob("NB_BOIDS_PC");
+    d->boids_tile = read_knob("NB_BOIDS_TILE");
+    d->boids_force = read_knob("NB_BOIDS_FORCE");
+    d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
+    d->shard_rccl_solo = read_knob("NB_SHARD_RCCL_SOLO");
+    d->generation = generation;
+    return d;
+}
+
+const DebugOverrides &overrides()
+{
+    const DebugOverrides *d = g_overrides.load(std::memory_order_acquire);
+    if (d) return *d;
+    std::lock_guard<std::mutex> lock(g_overrides_mu);
+    d = g_overrides.load(std::memory_order_acquire);
+    if (!d) {
+        d = parse_overrides(1);
+        g_overrides.store(d, std::memory_order_release);
+    }
+    return *d;
 }
 
 bool valid_tile(uint32_t t) { return t == 256 || t == 512 || t == 1024; }
@@ -51,6 +111,7 @@ struct Plan {
     uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
     uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
     uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
+    uint32_t spin_budget;                   // block chain: polls per wait, 0 = kernel default (NB_BC_SPIN_BUDGET: the give-up test)
     uint32_t n_total;                       // the set size the plan was made for
 };
 
@@ -72,12 +133,10 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         *err = "nb: params.mode must be NB_MODE_STRICT or NB_MODE_FAST";
         return NB_ERR_INVALID;
     }
+    const DebugOverrides &dbg = overrides();
     Plan pl{};
     pl.tile = p.tile;
-    if (pl.tile == 0) {
-        pl.tile = (p.mode == NB_MODE_STRICT) ? 1024u : 512u;
-        env_u32("NB_TILE", &pl.tile);
-    }
+    if (pl.tile == 0) pl.tile = dbg.tile.or_else((p.mode == NB_MODE_STRICT) ? 1024u : 512u);
     if (!valid_tile(pl.tile)) {
         *err = "nb: params.tile must be 0, 256, 512 or 1024";
         return NB_ERR_INVALID;
@@ -88,12 +147,10 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (p.mode == NB_MODE_FAST) {
         // bodies per thread; two or four also let the thread's pairs share reciprocals (measured against all 131 072 bodies:
         // 131 072 / 65 536 / 32 768 bodies: 4 is fastest; 16 384: 2 -- 0.361 ms against 0.373 (1) and 0.375 (4))
-        pl.ib = (count >= 32768u) ? 4u : (count >= 16384u) ? 2u : 1u;  // (standalone sets of 8 192: 1 is fastest)
-        env_u32("NB_FAST_IB", &pl.ib);
+        pl.ib = dbg.fast_ib.or_else((count >= 32768u) ? 4u : (count >= 16384u) ? 2u : 1u);  // (standalone sets of 8 192: 1 is fastest)
         if (pl.ib != 1 && pl.ib != 2 && pl.ib != 4) pl.ib = 1;
         const uint32_t blocks = (count + 256u * pl.ib - 1u) / (256u * pl.ib);
-        uint32_t slices = (kTargetWaves + blocks * 4u - 1u) / (blocks * 4u);
-        env_u32("NB_FAST_SLICES", &slices);
+        uint32_t slices = dbg.fast_slices.or_else((kTargetWaves + blocks * 4u - 1u) / (blocks * 4u));
         const uint32_t max_by_tiles = (n_total + pl.tile - 1u) / pl.tile;
         if (slices > max_by_tiles) slices = max_by_tiles;
         if (slices > kMaxSlices) slices = kMaxSlices;
@@ -129,19 +186,15 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
             pl.guard_c = c;
         }
     }
-    uint32_t f = 0;
-    if (env_u32("NB_STRICT_FORCE_IEEE", &f) && f) pl.force_ieee = 1;
+    if (dbg.strict_force_ieee.on()) pl.force_ieee = 1;
     if (p.mode == NB_MODE_FAST) {
         // FAST reuses the field: 1 = never share a reciprocal between two pairs (the product of two r^2 must stay normal:
         // bias in [2^-60, 2^60]; coordinates are checked per tile on the device).  NB_FAST_NO_SHARE=1: tests, measurements.
         const bool bias_ok = std::isfinite(p.bias) && p.bias >= 0x1p-60f && p.bias <= 0x1p60f;
-        f = 0;
-        pl.force_ieee = (!bias_ok || (env_u32("NB_FAST_NO_SHARE", &f) && f)) ? 1u : 0u;
+        pl.force_ieee = (!bias_ok || dbg.fast_no_share.on()) ? 1u : 0u;
     }
-    f = 0;
-    pl.force_3d = (env_u32("NB_FORCE_3D", &f) && f) ? 2u : 0u;
-    f = 0;
-    pl.no_packed = (env_u32("NB_STRICT_NO_PACKED", &f) && f) ? 1u : 0u;
+    pl.force_3d = dbg.force_3d.on() ? 2u : 0u;
+    pl.no_packed = dbg.strict_no_packed.on() ? 1u : 0u;
     // STRICT cannot split the fold over j (the sum is sequential), so a small shard would leave SIMDs idle:
     // below 65 536 bodies give each body S lanes until the shard supplies 2 waves per SIMD (256 CUs x 4 SIMDs x 2 =
     // 2048 waves).  The DPP adds of the j-parallel form cost about twice a plain add, so S = 1 stays ahead down to
@@ -149,32 +202,28 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     pl.lanes = 1;
     if (count < 65536u)
         while (pl.lanes < 16 && (uint64_t)count * pl.lanes < 2048ull * 64ull) pl.lanes *= 2;
-    env_u32("NB_STRICT_LANES", &pl.lanes);
+    pl.lanes = dbg.strict_lanes.or_else(pl.lanes);
     if (pl.lanes != 1 && pl.lanes != 2 && pl.lanes != 4 && pl.lanes != 8 && pl.lanes != 16) pl.lanes = 1;
-    pl.unroll = pl.lanes == 1 ? 8 : (pl.lanes == 16 ? 2 : 4);
-    env_u32("NB_STRICT_UNROLL", &pl.unroll);
+    pl.unroll = dbg.strict_unroll.or_else(pl.lanes == 1 ? 8 : (pl.lanes == 16 ? 2 : 4));
     if (pl.lanes == 1 && pl.unroll != 4 && pl.unroll != 8 && pl.unroll != 16) pl.unroll = 8;
     if (pl.lanes > 1 && pl.unroll != 2 && pl.unroll != 4) pl.unroll = 4;
     if (pl.lanes == 16) pl.unroll = 2;
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 512) pl.tile = 1024;  // built j-parallel shapes: 256, 1024
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 1024 && pl.unroll == 2 && pl.lanes < 8) pl.unroll = 4;
-    // Producer/consumer form (14 producers + 2 consumers per 64 bodies) for every shard below 65 536 bodies: measured
-    // at N = 131 072 (profiles/r01_jp/pc_sweep.log): 16 384 bodies 1.35 ms (j-parallel S=8: 2.30), 32 768: 2.66 (S=4: 3.55),
-    // 65 536: 5.31 -- there one lane per body wins again (4.77).
-    pl.pc = (count < 65536u) ? 14u : 0u;
-    env_u32("NB_STRICT_PC", &pl.pc);
+    // Shards of up to 65 536 bodies cannot fill the chip with one lane per body (the running sum is a serial chain per
+    // body).  Default there: the block-chain form (nb_nbody_bc.inc).  Against all 131 072 bodies: 16 384 bodies 0.85 ms
+    // (producer/consumer, 14 producers + 2 consumers per 64 bodies: 1.15; j-parallel S = 8: 2.1), 32 768: 1.67 (2.28),
+    // 65 536: 3.30 (one lane per body 3.52); the whole set: 6.57 against 6.19 for one lane per body, which therefore keeps
+    // everything above (profiles/r01_final/pc_sweep.log).  It needs scratch memory (nb_scratch_bytes).  Sets below 4 096
+    // bodies stay with producer/consumer: there the block chain's extra launch costs more than the form gains.
+    // Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns the block chain off; NB_STRICT_BC=0/1 decides outright.
+    pl.pc = dbg.strict_pc.or_else((count < 65536u) ? 14u : 0u);
     if (pl.pc == 1) pl.pc = 8;
     if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
-    // Up to 65 536 bodies per rank the block-chain form (nb_nbody_bc.inc) is the default.  Against all 131 072 bodies:
-    // 16 384 bodies 0.85 ms (producer/consumer 1.15), 32 768: 1.67 (2.28), 65 536: 3.30 (one lane per body 3.52); the whole
-    // set: 6.57 against 6.19 for one lane per body, which therefore keeps everything above.  It needs scratch memory
-    // (nb_scratch_bytes).  Sets below 4 096 bodies stay with producer/consumer: there the two extra launches cost more
-    // than the form gains.  Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns it off; NB_STRICT_BC=0/1 decides outright.
     pl.n_total = n_total;
-    uint32_t named = 0;
-    pl.bc = (count <= 65536u && n_total >= 4096u && !env_u32("NB_STRICT_PC", &named) && !env_u32("NB_STRICT_LANES", &named)) ? 1u : 0u;
-    env_u32("NB_STRICT_BC", &pl.bc);
+    pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= 4096u && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
+    pl.spin_budget = dbg.bc_spin_budget.or_else(0u);
     *out = pl;
     return NB_OK;
 }
@@ -185,8 +234,135 @@ size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
 
+// The launch API is stateless; a rank calls it with the same shape every step.  A few plans per thread are kept, keyed by
+// everything make_plan reads (no lock: one thread drives one GPU).
+int cached_plan(const nb_params &p, uint32_t n_total, uint32_t count, const Plan **out, std::string *err)
+{
+    struct Entry {
+        bool valid = false;
+        nb_params p{};
+        uint32_t n_total = 0, count = 0, generation = 0;
+        Plan pl{};
+    };
+    constexpr int kEntries = 4;
+    thread_local Entry cache[kEntries];
+    thread_local int next = 0;
+    const uint32_t gen = overrides().generation;
+    for (int i = 0; i < kEntries; ++i) {
+        const Entry &e = cache[i];
+        if (e.valid && e.n_total == n_total && e.count == count && e.generation == gen && std::memcmp(&e.p, &p, sizeof(p)) == 0) {
+            *out = &e.pl;
+            return NB_OK;
+        }
+    }
+    Plan pl;
+    int rc = make_plan(p, n_total, count, &pl, err);
+    if (rc != NB_OK) return rc;
+    Entry &e = cache[next];
+    next = (next + 1) % kEntries;
+    e.valid = true;
+    e.p = p;
+    e.n_total = n_total;
+    e.count = count;
+    e.generation = gen;
+    e.pl = pl;
+    *out = &e.pl;
+    return NB_OK;
+}
+
+// ---- sticky device status ------------------------------------------------------------------------------------
+// One word per device, owned by the library, zero at allocation.  The block-chain kernel ORs 1 into it when a wave gave
+// up waiting for its turn (its workgroup's outputs are NaN then).  check_device_status() -- called by every entry point
+// that waits for the device -- turns a set word into NB_ERR_STATE and clears it.
+constexpr int kMaxDevices = 64;
+uint32_t *g_status_word[kMaxDevices] = {};
+std::mutex g_status_mu;
+
+int device_status_word(uint32_t **out, std::string *err)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        *err = std::string("nb: hipGetDevice failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    if (!g_status_word[dev]) {
+        uint32_t *w = nullptr;
+        e = hipMalloc((void **)&w, 64);
+        if (e == hipSuccess) e = hipMemset(w, 0, 64);
+        if (e != hipSuccess) {
+            *err = std::string("nb: allocating the device status word failed: ") + hipGetErrorString(e);
+            return e == hipErrorOutOfMemory ? NB_ERR_ALLOC : NB_ERR_HIP;
+        }
+        g_status_word[dev] = w;
+    }
+    *out = g_status_word[dev];
+    return NB_OK;
+}
+
+// The caller has already waited for the work in question.  NB_OK, or NB_ERR_STATE (and the word cleared) if a kernel
+// reported a failure through `w` since the last check.
+int check_status_word(uint32_t *w, std::string *err)
+{
+    if (!w) return NB_OK;  // no block-chain launch yet
+    uint32_t v = 0;
+    hipError_t e = hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        *err = std::string("nb: reading the device status word failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    if (v == 0u) return NB_OK;
+    (void)hipMemset(w, 0, sizeof(v));
+    *err = "nb: a STRICT block-chain workgroup gave up waiting for its turn (its outputs are NaN): the state is invalid; "
+           "upload it again";
+    return NB_ERR_STATE;
+}
+
+// the launch API's word: the current device's
+int check_device_status(std::string *err)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return NB_OK;
+    uint32_t *w;
+    {
+        std::lock_guard<std::mutex> lock(g_status_mu);
+        w = g_status_word[dev];
+    }
+    return check_status_word(w, err);
+}
+
+// a context's / shard's own word (allocated at the first block-chain launch), so that one object's failure is not
+// reported to another; `dirty` = a block-chain launch since the last check (keeps the check off paths that never use it)
+struct StatusWord {
+    uint32_t *w = nullptr;
+    bool dirty = false;
+};
+
+int status_word_for_launch(StatusWord *sw, std::string *err)
+{
+    if (!sw->w) {
+        hipError_t e = hipMalloc((void **)&sw->w, 64);
+        if (e == hipSuccess) e = hipMemset(sw->w, 0, 64);
+        if (e != hipSuccess) {
+            *err = std::string("nb: allocating the status word failed: ") + hipGetErrorString(e);
+            return e == hipErrorOutOfMemory ? NB_ERR_ALLOC : NB_ERR_HIP;
+        }
+    }
+    sw->dirty = true;
+    return NB_OK;
+}
+
+int check_status(StatusWord *sw, std::string *err)
+{
+    if (!sw->dirty) return NB_OK;
+    sw->dirty = false;
+    return check_status_word(sw->w, err);
+}
+
 int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, uint32_t first, uint32_t count,
-                        const void *pos_in, void *pos_out, void *vel, void *scratch, hipStream_t stream, std::string *err)
+                        const void *pos_in, void *pos_out, void *vel, void *scratch, hipStream_t stream, std::string *err,
+                        StatusWord *sw = nullptr)
 {
     nbk::StepArgs a{};
     a.pos_in = (const float4 *)pos_in;
@@ -204,9 +380,15 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.force_ieee = pl.force_ieee;
     a.force_3d = pl.force_3d;
     a.j_chunk = pl.j_chunk;
-    if (pl.bc) { uint32_t dbg = 0; env_u32("NB_BC_DEBUG", &dbg); a.j_chunk = dbg; }
     a.no_packed = pl.no_packed;
-    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, stream)
+    a.spin_budget = pl.spin_budget;
+    uint32_t *status = nullptr;
+    if (p.mode == NB_MODE_STRICT && pl.bc) {
+        int rc = sw ? status_word_for_launch(sw, err) : device_status_word(&status, err);
+        if (rc != NB_OK) return rc;
+        if (sw) status = sw->w;
+    }
+    hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, status, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
@@ -266,9 +448,7 @@ float sqrt_threshold(float r)
 // Measured at N = 131 072 (tools/sweep.py boidsshard): 65 536 bodies 6.68 ms against 7.82; 131 072: 13.4 against 8.5.
 uint32_t boids_use_pc(uint32_t count)
 {
-    uint32_t pc = count < 81920u ? 1u : 0u;
-    env_u32("NB_BOIDS_PC", &pc);
-    return pc;
+    return overrides().boids_pc.or_else(count < 81920u ? 1u : 0u);
 }
 
 int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,
@@ -278,8 +458,7 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
         *err = "nb: boids: need count > 0 and [first, first+count) inside n_total";
         return NB_ERR_INVALID;
     }
-    uint32_t t = p.tile ? p.tile : 1024u;
-    if (p.tile == 0) env_u32("NB_BOIDS_TILE", &t);
+    const uint32_t t = p.tile ? p.tile : overrides().boids_tile.or_else(1024u);
     if (!valid_tile(t)) {
         *err = "nb: boids params.tile must be 0, 256, 512 or 1024";
         return NB_ERR_INVALID;
@@ -299,9 +478,7 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
         *err = "nb: boids: neighbour counts are kept in binary32 and need n_total < 2^24";
         return NB_ERR_UNSUPPORTED;
     }
-    uint32_t ff = 0;
-    env_u32("NB_BOIDS_FORCE", &ff);
-    a.force_flags = ff & 3u;
+    a.force_flags = overrides().boids_force.or_else(0u) & 3u;
     *out = a;
     *tile = t;
     return NB_OK;
@@ -362,6 +539,7 @@ struct nb_ctx {
     float *xfer = nullptr;    // 22n floats [matrices 16n | positions 3n | velocities 3n]: one-copy round trip of the drop-in calls
     float *hxfer = nullptr;   // its pinned host twin
     void *scratch = nullptr;
+    StatusWord status;        // sticky failure word of this context's block-chain launches
     int cur = 0;
     bool uploaded = false;
     uint64_t steps = 0;
@@ -437,6 +615,7 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     if (ctx->xfer) (void)hipFree(ctx->xfer);
     if (ctx->hxfer) (void)hipHostFree(ctx->hxfer);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->status.w) (void)hipFree(ctx->status.w);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -554,7 +733,7 @@ NB_EXPORT int nb_step(nb_ctx *ctx, uint32_t k)
     }
     for (uint32_t s = 0; s < k; ++s) {
         int rc = launch_step_planned(ctx->p, ctx->plan, ctx->n, 0, ctx->n, ctx->pos[ctx->cur], ctx->pos[ctx->cur ^ 1],
-                                     ctx->vel, ctx->scratch, ctx->stream, &ctx->err);
+                                     ctx->vel, ctx->scratch, ctx->stream, &ctx->err, &ctx->status);
         if (rc != NB_OK) return rc;
         ctx->cur ^= 1;
         ctx->steps++;
@@ -673,7 +852,7 @@ NB_EXPORT int nb_sync(nb_ctx *ctx)
         return NB_ERR_INVALID;
     }
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NB_OK;
+    return check_status(&ctx->status, &ctx->err);
 }
 
 NB_EXPORT uint64_t nb_steps_done(const nb_ctx *ctx) { return ctx ? ctx->steps : 0; }
@@ -701,7 +880,7 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         if (inst_16n) std::memcpy(inst_16n, ctx->hxfer, n * 16 * sizeof(float));
         if (pos_xyz) std::memcpy(pos_xyz, ctx->hxfer + 16 * n, bytes);
         if (vel_xyz) std::memcpy(vel_xyz, ctx->hxfer + 19 * n, bytes);
-        return NB_OK;
+        return check_status(&ctx->status, &ctx->err);
     }
     if (pos_xyz) {
         NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->stage, ctx->stream));
@@ -721,7 +900,7 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (!pos_xyz && !vel_xyz && !inst_16n) NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NB_OK;
+    return check_status(&ctx->status, &ctx->err);
 }
 
 // ---- one-call drop-ins (src/main.rs:404-410, 443-449) ---------------------------------------------------
@@ -730,7 +909,7 @@ struct UpdateCache {
     std::mutex mu;
     nb_ctx *ctx = nullptr;
     nb_params p{};
-    std::vector<float> vel_full, tmp;
+    std::vector<float> pos_full, vel_full, tmp;
 };
 // never destroyed: a static destructor could run after the HIP runtime's own teardown
 UpdateCache &update_cache()
@@ -774,7 +953,7 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
     std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));
     std::memcpy(pos_out, c->hxfer + 16 * n, count * xyz);
     std::memcpy(vel_out, c->hxfer + 19 * n, count * xyz);
-    return NB_OK;
+    return check_status(&c->status, &c->err);
 }
 
 int update_common(const char *who, bool boids, float *inst, size_t n_inst, float *pos, size_t n_pos, float *opos, size_t n_opos,
@@ -794,12 +973,14 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     if (n_vel) std::memcpy(ovel, vel, n_vel * xyz);  // main.rs:416 / 460
     const size_t count = std::min(n_inst, std::min(n_pos, n_vel));  // zip, main.rs:420-423 / 465-469
     if (count == 0) return NB_OK;
-    if (n_pos > 0xffffffffull) {
+    // The set the device folds over.  n-body: old_positions (main.rs:425).  boids: the position folds run over
+    // old_positions.iter() (main.rs:471, 482) and the velocity fold over old_velocities.iter() (main.rs:494), each with its own
+    // length -- the reference never indexes one slice by the other's length -- so the device set is the longer of the two
+    // and the shorter snapshot is padded with NaN records: a NaN distance fails every `dist < radius` test (main.rs:475, 486,
+    // 498), so a padding record contributes to no sum and no count, exactly like an element that is not there.
+    const size_t n_set = boids ? std::max(n_pos, n_vel) : n_pos;
+    if (n_set > 0xffffffffull) {
         g_tls_error = std::string(who) + ": more than 2^32-1 bodies";
-        return NB_ERR_INVALID;
-    }
-    if (boids && n_vel < n_pos) {  // old_velocities[n] for every n < old_positions.len(), main.rs:494-496
-        g_tls_error = std::string(who) + ": velocities shorter than positions (the reference indexes old_velocities out of bounds)";
         return NB_ERR_INVALID;
     }
     nb_params p;
@@ -810,7 +991,7 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
 
     UpdateCache &uc = update_cache();
     std::lock_guard<std::mutex> lock(uc.mu);
-    const uint32_t n = (uint32_t)n_pos;
+    const uint32_t n = (uint32_t)n_set;
     if (!uc.ctx || uc.ctx->n != n || std::memcmp(&uc.p, &p, sizeof(p)) != 0) {
         if (uc.ctx) nb_destroy(uc.ctx);
         uc.ctx = nullptr;
@@ -818,9 +999,15 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
         if (rc != NB_OK) return update_fail(uc, who, rc);
         uc.p = p;
     }
-    const float *vel_src = ovel;
-    if (n_vel < n_pos) {  // n-body only: bodies past the zip are computed and dropped; give them a velocity to carry
-        uc.vel_full.assign(n_pos * 3, 0.f);
+    const float *pos_src = opos, *vel_src = ovel;
+    if (n_pos < n_set) {  // boids only
+        uc.pos_full.assign(n_set * 3, std::nanf(""));
+        std::memcpy(uc.pos_full.data(), opos, n_pos * xyz);
+        pos_src = uc.pos_full.data();
+    }
+    if (n_vel < n_set) {
+        // n-body: bodies past the zip are computed and dropped; give them a velocity to carry.  boids: see above.
+        uc.vel_full.assign(n_set * 3, boids ? std::nanf("") : 0.f);
         std::memcpy(uc.vel_full.data(), ovel, n_vel * xyz);
         vel_src = uc.vel_full.data();
     }
@@ -829,20 +1016,20 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
     int rc;
     if (n <= kRoundtripMax) {
-        rc = update_roundtrip(uc.ctx, boids, bp, opos, vel_src, count, pos, vel, inst);
+        rc = update_roundtrip(uc.ctx, boids, bp, pos_src, vel_src, count, pos, vel, inst);
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
-    rc = nb_upload(uc.ctx, opos, vel_src);
+    rc = nb_upload(uc.ctx, pos_src, vel_src);
     if (rc == NB_OK) rc = boids ? nb_step_boids(uc.ctx, 1, bp) : nb_step(uc.ctx, 1);
     if (rc != NB_OK) return update_fail(uc, who, rc);
-    if (count == n_pos) {  // the usual case: all three slices as long as the set
+    if (count == n_set) {  // the usual case: all three slices as long as the set
         rc = nb_download(uc.ctx, pos, vel, inst);
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
-    uc.tmp.resize(n_pos * 22);
-    float *pos_tmp = uc.tmp.data(), *vel_tmp = pos_tmp + 3 * n_pos, *inst_tmp = pos_tmp + 6 * n_pos;
+    uc.tmp.resize(n_set * 22);
+    float *pos_tmp = uc.tmp.data(), *vel_tmp = pos_tmp + 3 * n_set, *inst_tmp = pos_tmp + 6 * n_set;
     rc = nb_download(uc.ctx, pos_tmp, vel_tmp, inst_tmp);
     if (rc != NB_OK) return update_fail(uc, who, rc);
     std::memcpy(pos, pos_tmp, count * xyz);
@@ -878,6 +1065,7 @@ NB_EXPORT void nb_update_release(void)
     std::lock_guard<std::mutex> lock(uc.mu);
     if (uc.ctx) nb_destroy(uc.ctx);
     uc.ctx = nullptr;
+    uc.pos_full = std::vector<float>();
     uc.vel_full = std::vector<float>();
     uc.tmp = std::vector<float>();
 }
@@ -897,8 +1085,7 @@ NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64
     Plan pl;
     int rc = make_plan(p, 1024, 1024, &pl, &g_tls_error);
     if (rc != NB_OK) return rc;
-    uint32_t forced = 0;
-    if (pl.force_ieee && !(env_u32("NB_STRICT_FORCE_IEEE", &forced) && forced)) {
+    if (pl.force_ieee && !overrides().strict_force_ieee.on()) {
         g_tls_error = "nb_selftest_divide: these parameters have no guarded range (STRICT always divides with '/')";
         return NB_ERR_UNSUPPORTED;
     }
@@ -922,10 +1109,9 @@ NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64
     const uint64_t threads = (uint64_t)blocks * 256u;
     uint64_t per_thread = (pairs + threads - 1) / threads;
     if (per_thread > 0xffffffffull) per_thread = 0xffffffffull;
-    uint32_t control = 0;  // NB_SELFTEST_CONTROL=1: compare the UNCORRECTED product n*r instead (control arm: must report mismatches)
-    env_u32("NB_SELFTEST_CONTROL", &control);
+    const bool control = overrides().selftest_control.on();  // NB_SELFTEST_CONTROL=1: compare the UNCORRECTED product n*r instead (control arm: must report mismatches)
     if (e == hipSuccess)
-        e = nbk::launch_divide_selftest(blocks, seed, (uint32_t)per_thread, d_lo, d_hi, n_lo, n_hi, d_bad, d_pair, control != 0, nullptr);
+        e = nbk::launch_divide_selftest(blocks, seed, (uint32_t)per_thread, d_lo, d_hi, n_lo, n_hi, d_bad, d_pair, control, nullptr);
     unsigned long long bad = 0;
     float pair[2] = {0.f, 0.f};
     if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
@@ -952,8 +1138,7 @@ NB_EXPORT int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uin
     }
     int rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
-    uint32_t control = 0;  // NB_SELFTEST_CONTROL=1: the same steps on the UNREFINED reciprocal (control arm: must report mismatches)
-    env_u32("NB_SELFTEST_CONTROL", &control);
+    const bool control = overrides().selftest_control.on();  // NB_SELFTEST_CONTROL=1: the same steps on the UNREFINED reciprocal (control arm: must report mismatches)
     unsigned long long *d_bad = nullptr;
     float *d_pair = nullptr;
     hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
@@ -962,7 +1147,7 @@ NB_EXPORT int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uin
     if (e == hipSuccess) e = hipMemset(d_pair, 0, 2 * sizeof(float));
     const uint32_t slab = 1u << 13;  // 2^36 pairs per launch: a fraction of a second each, so no launch runs long
     for (uint32_t done = 0; e == hipSuccess && done < count; done += slab) {
-        e = nbk::launch_ladder_exhaustive(first_significand + done, std::min(slab, count - done), control != 0, d_bad, d_pair, nullptr);
+        e = nbk::launch_ladder_exhaustive(first_significand + done, std::min(slab, count - done), control, d_bad, d_pair, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     unsigned long long bad = 0;
@@ -1037,19 +1222,41 @@ NB_EXPORT int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t
         g_tls_error = "nb_launch_step: [first, first+count) exceeds n_total";
         return NB_ERR_INVALID;
     }
-    Plan pl;
-    int rc = make_plan(p, n_total, count, &pl, &g_tls_error);
+    const Plan *pl = nullptr;
+    int rc = cached_plan(p, n_total, count, &pl, &g_tls_error);
     if (rc != NB_OK) return rc;
-    const size_t need = plan_scratch_bytes(pl, count);
+    const size_t need = plan_scratch_bytes(*pl, count);
     if (need && (!scratch || scratch_bytes < need)) {
         g_tls_error = "nb_launch_step: scratch smaller than nb_scratch_bytes()";
         return NB_ERR_INVALID;
     }
     rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
-    rc = select_device_of(pos_in, &g_tls_error);
+    if (!stream) {  // a caller that brings a stream has made that stream's device current; the NULL stream says nothing
+        rc = select_device_of(pos_in, &g_tls_error);
+        if (rc != NB_OK) return rc;
+    }
+    return launch_step_planned(p, *pl, n_total, first, count, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+NB_EXPORT int nb_launch_status(void *stream)
+{
+    int rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
-    return launch_step_planned(p, pl, n_total, first, count, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_launch_status: hipStreamSynchronize failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return check_device_status(&g_tls_error);
+}
+
+NB_EXPORT int nb_debug_reload_env(void)
+{
+    std::lock_guard<std::mutex> lock(g_overrides_mu);
+    const DebugOverrides *old = g_overrides.load(std::memory_order_acquire);
+    g_overrides.store(parse_overrides(old ? old->generation + 1u : 1u), std::memory_order_release);
+    return NB_OK;
 }
 
 NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count,

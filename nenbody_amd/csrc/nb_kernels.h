@@ -18,6 +18,7 @@ struct StepArgs {
     uint32_t force_3d;          // 2 (= kFlagNonPlanar) = never take the planar (z == 0) shortcut (tests, measurements)
     uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
     uint32_t no_packed;         // STRICT: 1 = planar tiles take the component-packed fold instead of the j-packed one (tests, measurements)
+    uint32_t spin_budget;       // STRICT block chain: polls per wait before a wave gives up; 0 = the default (tests set a tiny one)
 };
 
 // Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
@@ -39,7 +40,8 @@ hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_NOSLP_TU
 hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s);  // producer/consumer form: 64 bodies x (2 + producers) waves per workgroup
 // block-chain form for small shards: quotients stay in registers, running sums pass from wave to wave; needs scratch
-hipError_t launch_strict_bc(const StepArgs &a, void *scratch, hipStream_t s);
+// `status`: a device word the kernel ORs 1 into when a wave gave up waiting (outputs poisoned): the host's sticky error
+hipError_t launch_strict_bc(const StepArgs &a, void *scratch, uint32_t *status, hipStream_t s);
 size_t strict_bc_scratch_bytes(uint32_t n_total);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);

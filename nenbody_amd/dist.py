@@ -185,8 +185,11 @@ class ShardedScene:
             self.step()
 
     def sync(self) -> None:
+        """Wait for the queued steps; raises NbError (NB_ERR_STATE) if a kernel reported a failure (``nb_launch_status``)."""
         if self.device.type == "cuda":
             self.torch.cuda.synchronize(self.device)
+            if self.backend.name == "hip":
+                check(self.backend.lib.nb_launch_status(self.torch.cuda.current_stream(self.device).cuda_stream))
 
     # -- state access -------------------------------------------------------------------------------------
     def positions(self) -> np.ndarray:

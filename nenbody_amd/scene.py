@@ -199,8 +199,8 @@ def update_instance_boids(instances, positions, old_positions, velocities, old_v
     """The reference's live controller with its own five arguments, updated in place (src/main.rs:443-449).
 
     Same contract as :func:`update_instance_nbody` (snapshot copies first, main.rs:459-460; `zip` stops at the
-    shortest of instances / positions / velocities, main.rs:465-469).  The velocity fold (main.rs:494-504) reads
-    ``old_velocities[n]`` for every body, so ``velocities`` may not be shorter than ``positions``.
+    shortest of instances / positions / velocities, main.rs:465-469).  The position folds run over all of
+    ``old_positions`` and the velocity fold (main.rs:494-504) over all of ``old_velocities``, each with its own length.
     One call of ``nb_update_instance_boids`` (include/nenbody.h).
     """
     _update_call(_lib.load().nb_update_instance_boids, instances, positions, old_positions, velocities, old_velocities, params)

@@ -61,17 +61,53 @@ def load() -> ctypes.CDLL:
         lib.nbo_boids_default_params.restype = None
         lib.nbo_boids_step_range.argtypes = [vp, vp, vp, vp, vp, u32, u32, u32, ctypes.POINTER(BoidsParams)]
         lib.nbo_boids_step_range.restype = None
+        lib.nbo_boids_step_range2.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, ctypes.POINTER(BoidsParams)]
+        lib.nbo_boids_step_range2.restype = None
         lib.nbo_boids_run.argtypes = [vp, vp, vp, u32, u32, ctypes.POINTER(BoidsParams), i]
         lib.nbo_boids_run.restype = i
         _lib = lib
     return _lib
 
 
-def ncores() -> int:
+def cpu_limits() -> dict:
+    """What this process may actually use: the affinity mask AND the cgroup CPU quota (a container is commonly given every
+    logical CPU in its mask but a quota of a few cores' worth of time: threads beyond the quota only get throttled).
+    `threads` = the worker count to use: min(affinity, ceil(quota))."""
     try:
-        return len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
-        return os.cpu_count() or 1
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except Exception:
+            pass
+    threads = affinity if quota is None else max(1, min(affinity, int(-(-quota // 1))))
+    return {"affinity": affinity, "cgroup_quota_cores": quota, "threads": threads}
+
+
+def throttled_usec() -> int:
+    """cgroup v2 cpu.stat throttled_usec (0 if unreadable): a run during which this grows was capped by the quota."""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1])
+    except Exception:
+        pass
+    return 0
+
+
+def ncores() -> int:
+    """Worker threads the oracle uses by default: the cores this process can really run on (cpu_limits)."""
+    return cpu_limits()["threads"]
 
 
 def init_state(n: int, seed: int = 1234):
@@ -151,6 +187,24 @@ def boids_step_range(old_pos, old_vel, first: int, count: int, params: BoidsPara
     load().nbo_boids_step_range(op.ctypes.data, ov.ctypes.data, p.ctypes.data, v.ctypes.data,
                                 inst.ctypes.data if want_instances else None, len(op), first, count, ctypes.byref(bp))
     return (p, v, inst) if want_instances else (p, v)
+
+
+def boids_update_instance(instances_len: int, positions, velocities, params: BoidsParams = None):
+    """update_instance_boids (main.rs:443-526) as the reference's free function behaves on slices of UNEQUAL length:
+    the position folds run over all of old_positions, the velocity fold over all of old_velocities, and the zip updates the
+    first min(len(instances), len(positions), len(velocities)) bodies.  Returns (new positions, new velocities, instances) of
+    that many bodies."""
+    op = np.ascontiguousarray(positions, np.float32)
+    ov = np.ascontiguousarray(velocities, np.float32)
+    bp = params if params is not None else boids_params()
+    count = min(int(instances_len), len(op), len(ov))
+    v = ov[:count].copy()
+    p = np.empty((count, 3), np.float32)
+    inst = np.zeros((count, 4, 4), np.float32)
+    if count:
+        load().nbo_boids_step_range2(op.ctypes.data, len(op), ov.ctypes.data, len(ov), p.ctypes.data, v.ctypes.data, inst.ctypes.data,
+                                     0, count, ctypes.byref(bp))
+    return p, v, inst
 
 
 def cameras(eyes, dirs, up, cp):

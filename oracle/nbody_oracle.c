@@ -286,9 +286,13 @@ static float dist2_f32(const float *a, const float *b) /* a.distance2(b) = (b - 
 
 /* One boids step for bodies [first, first+count) against the snapshots of ALL positions and velocities
  * (old_positions / old_velocities, main.rs:459-460).  pos3_out, vel3 (in: this range's velocities, out: new) and
- * inst16 use the local index (n - first). */
-NBO_API void nbo_boids_step_range(const float *old_pos3, const float *old_vel3, float *pos3_out, float *vel3, float *inst16,
-                                  uint32_t n_total, uint32_t first, uint32_t count, const nbo_boids_params *bp)
+ * inst16 use the local index (n - first).
+ * The two snapshots have their own lengths: the position folds run over old_positions.iter() (main.rs:471, 482), the
+ * velocity fold over old_velocities.iter() (main.rs:494) -- nothing in the reference indexes one by the other's length,
+ * and the zip (main.rs:465-469) only bounds which bodies n are updated (first + count <= min of the lengths). */
+NBO_API void nbo_boids_step_range2(const float *old_pos3, uint32_t n_total, const float *old_vel3, uint32_t n_total_vel,
+                                   float *pos3_out, float *vel3, float *inst16, uint32_t first, uint32_t count,
+                                   const nbo_boids_params *bp)
 {
     for (uint32_t l = 0; l < count; ++l) {
         const uint32_t n = first + l;
@@ -322,7 +326,7 @@ NBO_API void nbo_boids_step_range(const float *old_pos3, const float *old_vel3, 
         /* main.rs:494-504  (flock_match, vcount) over the velocity snapshot */
         float mx = 0.0f, my = 0.0f, mz = 0.0f;
         int32_t vcnt = 0;
-        for (uint32_t i = 0; i < n_total; ++i) {
+        for (uint32_t i = 0; i < n_total_vel; ++i) {
             const float *vi = old_vel3 + 3 * (size_t)i;
             const float dist = sqrtf(dist2_f32(v, vi));            /* main.rs:497 boid_n_vel.distance(*boid_i_vel) */
             if (dist < bp->rule_3_distance && n != i) {            /* main.rs:498 */
@@ -368,6 +372,12 @@ NBO_API void nbo_boids_step_range(const float *old_pos3, const float *old_vel3, 
         /* main.rs:522-524 */
         if (inst16) instance_matrix(inst16 + 16 * (size_t)l, p, v);
     }
+}
+
+NBO_API void nbo_boids_step_range(const float *old_pos3, const float *old_vel3, float *pos3_out, float *vel3, float *inst16,
+                                  uint32_t n_total, uint32_t first, uint32_t count, const nbo_boids_params *bp)
+{
+    nbo_boids_step_range2(old_pos3, n_total, old_vel3, n_total, pos3_out, vel3, inst16, first, count, bp);
 }
 
 typedef struct {

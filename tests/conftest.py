@@ -32,3 +32,35 @@ def nb():
 
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def monkeypatch():
+    """pytest's monkeypatch, plus: the library reads its NB_* diagnostic overrides once per process (no launch path calls
+    getenv), so setting / restoring one of them makes the library read them again (``nb_debug_reload_env``)."""
+    from _pytest.monkeypatch import MonkeyPatch
+
+    def reload():
+        import nenbody_amd._lib as _lib
+
+        if _lib._lib is not None:  # only once the library is loaded; a fresh load reads the environment itself
+            _lib._lib.nb_debug_reload_env()
+
+    class NbMonkeyPatch(MonkeyPatch):
+        def setenv(self, name, value, prepend=None):
+            super().setenv(name, value, prepend)
+            if name.startswith("NB_"):
+                reload()
+
+        def delenv(self, name, raising=True):
+            super().delenv(name, raising)
+            if name.startswith("NB_"):
+                reload()
+
+        def undo(self):
+            super().undo()
+            reload()
+
+    mp = NbMonkeyPatch()
+    yield mp
+    mp.undo()

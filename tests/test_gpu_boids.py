@@ -218,8 +218,7 @@ def test_update_instance_boids_other_constants_every_other_frame(nb, oracle):
 
 
 def test_update_instance_boids_zip_truncation_and_frames(nb, oracle):
-    """instances shorter than positions: only that many bodies move while the folds see everyone (main.rs:465-471);
-    velocities shorter than positions is where the reference indexes old_velocities out of bounds (main.rs:496)."""
+    """instances shorter than positions: only that many bodies move while the folds see everyone (main.rs:465-471)."""
     n, m = 300, 40
     pos, vel = cloud(oracle, n, seed=22)
     p_ref, v_ref = oracle.boids_step_range(pos, vel, 0, m)
@@ -230,9 +229,6 @@ def test_update_instance_boids_zip_truncation_and_frames(nb, oracle):
     assert_bits_equal(velocities[:m], v_ref)
     assert_bits_equal(positions[m:], pos[m:])
     assert_bits_equal(velocities[m:], vel[m:])
-    with pytest.raises(ValueError, match="out of bounds"):
-        nb.update_instance_boids(np.zeros((n, 4, 4), np.float32), positions, np.zeros_like(pos), velocities[:m].copy(),
-                                 np.zeros((m, 3), np.float32))
     # frame after frame on the same Vecs, alternating with the n-body function (they share the cached context)
     positions, velocities = pos.copy(), vel.copy()
     old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
@@ -247,6 +243,31 @@ def test_update_instance_boids_zip_truncation_and_frames(nb, oracle):
             p_ref, v_ref = oracle.run(p_ref, v_ref, 1)
         assert_bits_equal(positions, p_ref, f"frame {frame}")
         assert_bits_equal(velocities, v_ref, f"frame {frame}")
+
+
+@pytest.mark.parametrize("n_inst,n_pos,n_vel", [(300, 300, 40), (300, 40, 300), (25, 300, 40), (200, 180, 190), (5000, 5000, 4100),
+                                                  (20000, 17000, 20000)])
+def test_update_instance_boids_slices_of_unequal_length(nb, oracle, n_inst, n_pos, n_vel):
+    """positions and velocities of different lengths: rule 1 and rule 2 fold over old_positions.iter() (main.rs:471, 482),
+    rule 3 over old_velocities.iter() (main.rs:494) -- each its own length, neither indexed by the other's -- and the zip
+    (main.rs:465-469) updates the first min(len) bodies.  Nothing panics in the reference; nothing is refused here."""
+    pos, _ = cloud(oracle, n_pos, seed=41)
+    _, vel = cloud(oracle, n_vel, seed=42)
+    m = min(n_inst, n_pos, n_vel)
+    p_ref, v_ref, i_ref = oracle.boids_update_instance(n_inst, pos, vel)
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n_inst, 4, 4), np.float32)
+    nb.update_instance_boids(inst, positions, old_p, velocities, old_v)
+    assert_bits_equal(old_p, pos, "old_positions = copy of positions (main.rs:459)")
+    assert_bits_equal(old_v, vel, "old_velocities = copy of velocities (main.rs:460)")
+    assert_bits_equal(positions[:m], p_ref, "positions")
+    assert_bits_equal(velocities[:m], v_ref, "velocities")
+    assert_bits_equal(positions[m:], pos[m:], "bodies past the zip keep their positions")
+    assert_bits_equal(velocities[m:], vel[m:], "bodies past the zip keep their velocities")
+    assert np.abs(inst[:m, 3, :3] - p_ref).max() == 0.0
+    np.testing.assert_allclose(inst[:m], i_ref, atol=1e-6, rtol=0)
+    assert not inst[m:].any()
 
 
 def test_boids_sharded_launch_equals_unsharded(nb, oracle):

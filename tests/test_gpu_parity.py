@@ -758,3 +758,64 @@ def test_selftest_refuses_parameters_without_a_guarded_range(nb):
     p.bias = 0.0            # no softening: d can be 0 -> STRICT always uses the IEEE divide
     bad = ctypes.c_uint64(0)
     assert _lib.load().nb_selftest_divide(ctypes.byref(p), 1024, 1, ctypes.byref(bad), None) == _lib.NB_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the block chain's give-up path is an ERROR at the ABI, never NaN with NB_OK
+# ---------------------------------------------------------------------------------------------------------
+def test_block_chain_give_up_is_reported_as_an_error(nb, oracle, monkeypatch):
+    """A wave of the block-chain kernel that exhausts its polls stops waiting (so the grid drains) and poisons its
+    workgroup's outputs; the library must then fail the next call that waits for the device with NB_ERR_STATE.
+    NB_BC_SPIN_BUDGET=1 (one poll per wait) forces it.  Afterwards the same process runs the same set correctly."""
+    from nenbody_amd import _lib
+
+    n = 8192
+    pos, vel = oracle.init_state(n, seed=77)
+    monkeypatch.setenv("NB_STRICT_BC", "1")
+    monkeypatch.setenv("NB_BC_SPIN_BUDGET", "1")
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(1)
+        with pytest.raises(nb.NbError) as e:
+            sc.sync()
+        assert e.value.status == _lib.NB_ERR_STATE and "gave up" in str(e.value)
+        sc.sync()  # reported once; the word is cleared
+    with nb.Scene(pos, vel) as sc:  # the download path reports it too
+        sc.step_n(1)
+        with pytest.raises(nb.NbError) as e:
+            sc.state()
+        assert e.value.status == _lib.NB_ERR_STATE
+    # launch API: nb_launch_status
+    import torch
+
+    sh = nb.ShardedScene(pos, vel, world=1, rank=0)
+    sh.step()
+    with pytest.raises(nb.NbError) as e:
+        sh.sync()
+    assert e.value.status == _lib.NB_ERR_STATE
+    sh.sync()
+    del sh
+    torch.cuda.synchronize()
+    monkeypatch.delenv("NB_BC_SPIN_BUDGET")
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(2)
+        sc.sync()
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 2)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+
+
+def test_block_chain_ieee_fallback_in_the_same_kernel(nb, oracle, monkeypatch):
+    """The IEEE-divide form of the block chain is a function call inside the one kernel: data that leaves the ladder's
+    proven range (a coordinate of 2^21, an infinity) must select it and give the oracle's bits, for own and foreign bodies."""
+    n = 6000
+    pos, vel = state3d(oracle, n, seed=5)
+    pos[17, 0] = np.float32(2.0 ** 21)      # outside [2^-43, 2^20]
+    pos[4000, 1] = np.float32(-3.0e-30)     # tiny, outside the range too
+    monkeypatch.setenv("NB_STRICT_BC", "1")
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(2)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 2)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Host + launch + exchange overhead of one multi-GPU step, measured on ONE GPU (diagnostic tool; needs a GPU).
+
+    python -u tools/step_overhead.py [COUNT [N_TOTAL [STEPS]]]          # default: 16384 of 131072, 200 steps
+
+What an 8-GPU run adds to the kernels is (a) the host work per step, (b) the dispatch gaps between the launches of a step
+and (c) the all-gather's own launch; (c)'s wire time needs 8 GPUs, everything else does not.  This tool runs rank 0's
+share of an 8-rank job -- bodies [0, COUNT) of N_TOTAL -- for STEPS steps with the exchange issued on a communicator of
+ONE rank (RCCL's whole call path, nothing on the wire), and reports
+
+    wall/step   host clock around the loop, one synchronisation at the end
+    dev/step    device time of the step's kernels (events around the launches, exchange excluded)
+    overhead    wall - dev
+
+for ShardedScene (Python: nb_launch_step + torch.distributed, what bench.py --gpus N runs) and NativeShard (the C loop
+nb_shard_step(k) with ncclAllGather on the same stream), STRICT and FAST.
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import nenbody_amd as nb  # noqa: E402
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+world = n // count
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+pos, vel = nb.init_state(n, 1234)
+
+
+class SoloScene(nb.ShardedScene):
+    """rank 0 of `world`, with the exchange issued on the one-rank group: in place on this rank's own slot"""
+
+    def _all_gather_slots(self, buf):
+        mine = buf[: self.slot]
+        self.dist.all_gather_into_tensor(mine, mine)
+
+
+def python_path(mode, exchange=True):
+    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0)
+    if not exchange:
+        sc._all_gather_slots = lambda buf: None
+    for _ in range(10):
+        sc.step()
+    sc.sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    real = sc.backend.step
+
+    def timed(*a, **kw):
+        e0, e1 = ev[timed.i]
+        timed.i += 1
+        e0.record()
+        real(*a, **kw)
+        e1.record()
+
+    # pass 1: wall clock, nothing else in the loop
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc.step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    # pass 2: device time of the step's kernels
+    timed.i = 0
+    sc.backend.step = timed
+    for _ in range(steps):
+        sc.step()
+    torch.cuda.synchronize()
+    sc.backend.step = real
+    dev = sum(a.elapsed_time(b) for a, b in ev) / steps * 1e-3
+    sc.sync()
+    return wall, dev
+
+
+def native_path(mode):
+    os.environ["NB_SHARD_RCCL_SOLO"] = "1"
+    nb.reload_env()
+    sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id())
+    sh.step(10)
+    sh.sync()
+    t0 = time.perf_counter()
+    sh.step(steps)
+    sh.sync()
+    wall = (time.perf_counter() - t0) / steps
+    sh.close()
+    os.environ.pop("NB_SHARD_RCCL_SOLO")
+    nb.reload_env()
+    return wall
+
+
+print(f"rank 0's share: {count} of {n} bodies (world {world}), {steps} steps; exchange = RCCL all-gather on a one-rank communicator")
+for name, mode in (("STRICT", nb.NB_MODE_STRICT), ("FAST", nb.NB_MODE_FAST)):
+    w_noex, dev = python_path(mode, exchange=False)
+    w_py, dev2 = python_path(mode)
+    w_c = native_path(mode)
+    print(f"{name:6s} dev/step {dev * 1e6:8.1f} us (with the exchange between steps: {dev2 * 1e6:8.1f})", flush=True)
+    print(f"{name:6s} ShardedScene, no exchange : wall/step {w_noex * 1e6:8.1f} us  overhead {(w_noex - dev) * 1e6:7.1f} us", flush=True)
+    print(f"{name:6s} ShardedScene + all-gather : wall/step {w_py * 1e6:8.1f} us  overhead {(w_py - dev) * 1e6:7.1f} us", flush=True)
+    print(f"{name:6s} NativeShard  + all-gather : wall/step {w_c * 1e6:8.1f} us  overhead {(w_c - dev) * 1e6:7.1f} us", flush=True)
+dist.destroy_process_group()

@@ -35,6 +35,7 @@ for rnd in range(rounds):
             for k in ("NB_STRICT_PC", "NB_STRICT_LANES", "NB_STRICT_BC"):
                 os.environ.pop(k, None)
             os.environ.update(env)
+            nb.reload_env()
             params = nb.default_params()
             cur, nxt = base.clone(), base.clone()
             vels = []

@@ -16,6 +16,7 @@ import nenbody_amd as nb  # noqa: E402
 def run(n, mode, steps, env):
     for k, v in env.items():
         os.environ[k] = str(v)
+        nb.reload_env()
     pos, vel = nb.init_state(n, 1234)
     with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
         sc.step_n(2)
@@ -26,6 +27,7 @@ def run(n, mode, steps, env):
         dt = (time.perf_counter() - t0) / steps
     for k in env:
         os.environ.pop(k, None)
+        nb.reload_env()
     pairs = float(n) * n / dt
     print(f"mode={'strict' if mode == 0 else 'fast'} n={n:8d} {env} ms/step={dt * 1e3:9.3f} pairs/s={pairs:.3e} "
           f"TF18={pairs * 18 / 1e12:6.1f} ({pairs * 18 / 157.3e12 * 100:4.1f}%)", flush=True)
@@ -46,6 +48,7 @@ def shard_sweep(n_total=131072):
         for env in ({}, {"NB_FORCE_3D": 1}):
             for k, v in env.items():
                 os.environ[k] = str(v)
+                nb.reload_env()
             base = None
             for world in (1, 2, 4, 8):
                 count = n_total // world
@@ -67,6 +70,7 @@ def shard_sweep(n_total=131072):
                       f"compute-only speedup={base / dt:5.2f}", flush=True)
             for k in env:
                 os.environ.pop(k, None)
+                nb.reload_env()
 
 
 def lanes_sweep(n_total=131072):
@@ -93,6 +97,7 @@ def lanes_sweep(n_total=131072):
                         env = {"NB_STRICT_LANES": lanes, "NB_STRICT_UNROLL": unroll, "NB_FORCE_3D": f3d}
                         for k, v in env.items():
                             os.environ[k] = str(v)
+                            nb.reload_env()
                         params = nb.default_params(mode=nb.NB_MODE_STRICT, tile=tile)
                         v4 = torch.zeros((count, 4), device=dev)
                         try:
@@ -149,7 +154,9 @@ def main():
                 count = n_total // world
                 for pc in (0, 1):
                     os.environ["NB_BOIDS_PC"] = str(pc)
+                    nb.reload_env()
                     os.environ["NB_BOIDS_FORCE"] = str(f3d)
+                    nb.reload_env()
                     for _ in range(2):
                         be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
                     torch.cuda.synchronize()
@@ -200,6 +207,7 @@ def main():
                     env = {"NB_STRICT_PC": 14 if pc == "bc" else pc, "NB_STRICT_BC": 1 if pc == "bc" else 0, "NB_FORCE_3D": f3d}
                     for k, v in env.items():
                         os.environ[k] = str(v)
+                        nb.reload_env()
                     params = nb.default_params(mode=nb.NB_MODE_STRICT)
                     v4 = torch.zeros((count, 4), device=dev)
                     sb = be.scratch_bytes(params, n_total, count)
