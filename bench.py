@@ -10,10 +10,15 @@ reference constants (src/main.rs:411-413); a "step" is one update_instance_nbody
 GPUs the set is sharded by index range (strong scaling: total work fixed) and positions are all-gathered
 once per step (RCCL).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0.  `value` = body-updates/s = N * steps / s of the whole job.
-`roofline` prices the pair-fold kernel against the fp32 vector peak (the binding roofline: SURVEY.md
-section 8d) at the reference's 18 flop per interaction.  `cpu_baseline` is the CPU oracle
-(a C restatement of the reference's Rust; kind "port") timed on this host's cores.
+Prints ONE JSON line on rank 0.  `value` = body-updates/s = N * steps / s of the whole job, STRICT arithmetic (the
+reference's own, bit for bit) unless --mode fast.  `roofline` prices the pair-fold kernel against the fp32 vector peak
+(the binding roofline: SURVEY.md section 8d) at the reference's 18 flop per interaction, and carries the rate
+this device's vector ALU was measured to sustain in the same process (`measured_fma_ceiling`).  `cpu_baseline` is the CPU
+oracle (a C restatement of the reference's Rust; kind "port") timed on the host cores this process may really use.
+`targets` says which mode meets which line of BASELINE.json's north_star: no single mode meets both.
+
+Exit code: 0, or 3 when an informational leg (other mode, 3-D data, boids, CPU baseline) hung -- the headline line is
+still printed, with `aux_error` naming the leg.
 """
 import argparse
 import json
@@ -27,21 +32,49 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBPS = 8000.0            # same guide: HBM3E ~8 TB/s
 BYTES_PER_BODY_STEP = 64          # algorithmic HBM bytes: 16-B position + 16-B velocity record, read and written once
-
-
-def measured_traffic(kernel, n, count):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes, or None if this run's shape differs."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        if t["n"] == n and t["count"] == count:
-            return t["kernels"][kernel]["bytes_per_launch"]
-    except Exception:
-        pass
-    return None
 FLOP_PER_INTERACTION = 18         # src/main.rs:428-430 as written: 3 sub, 3 mul + 2 add, 1 add, 3 mul, 3 div, 3 add
+# What the kernels execute per interaction on the vector ALU, in full-rate lane-ops + quarter-rate
+# v_rcp_f32: the 18-flop figure above is the reference's NOMINAL count and is what `frac` is quoted against.
+EXECUTED_OPS = {
+    ("strict", "planar"): {"full_rate_ops": 18, "v_rcp_f32": 1.0, "note": "exact divide = 4 ops after a shared refined reciprocal"},
+    ("strict", "3d"): {"full_rate_ops": 26, "v_rcp_f32": 1.0},
+    ("fast", "planar"): {"full_rate_ops": 7.5, "v_rcp_f32": 0.5, "note": "two pairs share one reciprocal: 3 extra multiplies per two pairs"},
+    ("fast", "3d"): {"full_rate_ops": 10.5, "v_rcp_f32": 0.5},
+}
 
 
-def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel):
+def committed_traffic(nb, kernels, n, count):
+    """HBM bytes per step from the committed rocprofv3 --pmc passes (tools/pmc_summary.py --json), or (None, why).
+
+    bench.py cannot collect PMC counters itself; the file is refused when it was taken from other kernel sources, another
+    shape, or does not hold every kernel this step launches."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception as e:
+        return None, f"no usable profiles/hbm_traffic.json ({e.__class__.__name__})"
+    if t.get("src_sha") != nb._lib.kernel_source_sha():
+        return None, "profiles/hbm_traffic.json was measured on other kernel sources (src_sha differs): stale, not reported"
+    if t.get("n") != n or t.get("count") != count:
+        return None, "profiles/hbm_traffic.json is for another shape"
+    missing = [k for k in kernels if k not in t.get("kernels", {})]
+    if missing:
+        return None, f"profiles/hbm_traffic.json lacks {missing}"
+    return sum(t["kernels"][k]["bytes_per_launch"] for k in kernels), f"rocprofv3 --pmc passes committed under {t.get('source', 'profiles/')} (not measured in this run)"
+
+
+def step_kernels(nb, mode, n, count):
+    """the kernels one step launches, dominant one first (nb_api.hip:make_plan)"""
+    if mode == nb.NB_MODE_FAST:
+        return ["step_fast_kernel"]
+    if count > 65536:
+        return ["step_strict_kernel"]
+    return ["step_strict_bc_kernel", "planes_kernel"] if n >= 4096 else ["step_strict_pc_kernel"]
+
+
+def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None):
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     params = nb.default_params(mode=mode)
     sc = nb.ShardedScene(pos, vel, params)
     dev = sc.device
@@ -55,10 +88,10 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel):
     if world > 1:
         # untimed: bring the communicator and its channels up even when --warmup 0 (the target buffer is the scratch side)
         sc._all_gather_slots(sc.pos[sc.cur ^ 1])
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         sc.step()
     # kernel-only timing: events on the stream the kernel is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     real_step = sc.backend.step
 
     def timed_step(*a, **kw):
@@ -72,20 +105,18 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel):
     sc.backend.step = timed_step
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         sc.step()
     fence()
     t1 = time.perf_counter()
     sc.backend.step = real_step
+    sc.sync()  # nb_launch_status: a kernel-reported failure fails the bench instead of timing garbage
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count else 0.0
-    if mode == nb.NB_MODE_FAST:
-        kernel = "step_fast_kernel"
-    else:  # nb_api.hip:make_plan: one lane per body above 65 536 bodies per rank, block chain up to there (tiny sets: producer/consumer)
-        kernel = "step_strict_kernel" if sc.count > 65536 else ("step_strict_bc_kernel" if sc.n >= 4096 else "step_strict_pc_kernel")
-    return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "kernel": kernel}
+    return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps,
+            "kernels": step_kernels(nb, mode, sc.n, sc.count), "mode": "fast" if mode == nb.NB_MODE_FAST else "strict"}
 
 
 def main():
@@ -97,10 +128,10 @@ def main():
     ap.add_argument("--mode", choices=["strict", "fast"], default="strict",
                     help="arithmetic of the headline number: strict = bit-identical to the reference (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip timing the other mode")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs (other mode, 3-D data, boids)")
     ap.add_argument("--aux-timeout", type=float, default=180.0,
-                    help="seconds the informational legs (other mode, boids, CPU baseline) may take before the headline is "
-                         "printed without them")
+                    help="seconds the informational legs (other mode, 3-D data, boids, CPU baseline) may take before the headline "
+                         "is printed without them and the run exits 3")
     args = ap.parse_args()
 
     import torch
@@ -132,18 +163,21 @@ def main():
     primary = nb.NB_MODE_STRICT if args.mode == "strict" else nb.NB_MODE_FAST
     res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel)
 
-    def summarise(r):
-        steps_per_s = args.steps / r["elapsed_s"]
+    def summarise(r, data="planar"):
+        steps_per_s = r["steps"] / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
         achieved = FLOP_PER_INTERACTION * r["count"] * r["n"] / kernel_s / 1e12 if kernel_s > 0 else 0.0
-        traffic = measured_traffic(r["kernel"], r["n"], r["count"])
+        traffic, source = committed_traffic(nb, r["kernels"], r["n"], r["count"])
         roof = {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                "frac_is": "nominal: the reference's 18 flop per ordered pair (flop_per_interaction) over the spec fp32 vector peak",
                 "bound_note": "fp32 vector ALU (SURVEY.md 8d): an all-pairs fp32 fold is neither HBM- nor MFMA-bound; see 'hbm'",
-                "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                "traffic": traffic, "traffic_unit": "bytes/step (HBM, PMC)", "traffic_source": source,
                 "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
-                "kernel": r["kernel"],
-                "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"]}
+                "kernel": r["kernels"][0], "kernels_per_step": r["kernels"],
+                "kernel_ms": r["kernel_ms"],
+                "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"],
+                "executed_per_interaction": EXECUTED_OPS[(r["mode"], data)]}
         if traffic is not None and kernel_s > 0:  # how far from the HBM roofline the same launch is
             gbps = traffic / kernel_s / 1e9
             roof["hbm"] = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}
@@ -167,29 +201,54 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL backend, not a measurement)",
-        "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234), dt=0.1 G=0.001 bias=1e-7",
+        "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234; planar: z = 0 as main.rs:740,745), "
+                               "dt=0.1 G=0.001 bias=1e-7",
                    "mode": args.mode, "sharding": f"index range x{world}, all-gather of positions per step",
                    "tile": "library default"},
         "interactions_per_s": s["interactions_per_s"],
         "roofline": s["roofline"],
+        # BASELINE.json's north_star asks for >= 40 % of the fp32 roofline AND |dr| < 1e-4 against the reference after 1 000
+        # steps.  The system is chaotic: only arithmetic identical to the reference's holds the second
+        # line, and an exact binary32 divide costs 4 vector ops where the flop count says 1, which caps STRICT near 1/3.
+        "targets": {"roofline_40pct_met_by": "fast", "parity_1000_steps_met_by": "strict", "both_met_by": None,
+                    "note": "STRICT = the reference's arithmetic bit for bit (|dr| = 0 at any horizon) at ~0.32 of the fp32 "
+                            "peak; FAST = same law reassociated, above 0.40, |dr| < 1e-4 for ~100-200 steps only"},
     }
 
     # Everything after this point is informational.  If it wedges (a collective that never completes, say), the
-    # headline measured above must still be reported: the watchdog prints it and ends this rank.
+    # headline measured above must still be reported -- and the run must NOT look clean: the watchdog prints the line
+    # with the leg that was running and ends this rank with exit code 3.
     import threading
+
+    leg = {"name": "start"}
 
     def give_up():  # pragma: no cover
         if rank == 0:
-            line["aux_error"] = f"informational legs did not finish within {args.aux_timeout} s"
+            line["aux_error"] = f"informational leg '{leg['name']}' did not finish within {args.aux_timeout} s"
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     watchdog = threading.Timer(args.aux_timeout, give_up)
     watchdog.daemon = True
     watchdog.start()
 
+    if world == 1:
+        leg["name"] = "measured_fma_ceiling"
+        try:
+            import ctypes
+
+            tf = ctypes.c_double()
+            nb._lib.check(nb.load().nb_selftest_fma_rate(0.05, ctypes.byref(tf)))
+            line["roofline"]["measured_fma_ceiling"] = {
+                "achieved": tf.value, "unit": "TFLOP/s", "frac_of_spec_peak": tf.value / PEAK_FP32_VECTOR_TFLOPS,
+                "what": "independent v_fma_f32 on every SIMD (8 waves each) for 50 ms in this process: what this device's "
+                        "vector ALU issues at the clock it holds under load"}
+        except Exception as e:  # pragma: no cover
+            line["roofline"]["measured_fma_ceiling"] = {"error": repr(e)}
+
     if not args.no_secondary:
         other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
+        leg["name"] = "other_mode"
         try:
             o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel))
             line["other_mode"] = {"mode": "fast" if primary == nb.NB_MODE_STRICT else "strict",
@@ -197,41 +256,80 @@ def main():
         except Exception as e:  # pragma: no cover
             line["other_mode"] = {"error": repr(e)}
 
-    # the boids controller (update_instance_boids, main.rs:443-526), same set and sharding
-    try:
-        sc = nb.ShardedScene(pos, vel)
-        for _ in range(2):
-            sc.step_boids()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        bsteps = max(2, min(args.steps, 10))
-        t0 = time.perf_counter()
-        for _ in range(bsteps):
-            sc.step_boids()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
-        if world > 1:
-            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-        line["boids_controller"] = {"metric": "body-updates/s, update_instance_boids (bit-exact)",
-                                    "value": n * bsteps / float(bt.item()),
-                                    "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
-    except Exception as e:  # pragma: no cover
-        line["boids_controller"] = {"error": repr(e)}
+        # the same set with the planar shortcut switched off (NB_FORCE_3D=1): what 3-D data costs.  The reference's own
+        # initial state is planar and stays planar (z = 0, vz = 0 is a fixed point of its arithmetic), which the headline rides.
+        leg["name"] = "force_3d"
+        try:
+            os.environ["NB_FORCE_3D"] = "1"
+            nb.reload_env()
+            f3 = {}
+            for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
+                o = summarise(time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=max(3, min(args.steps, 10)), warmup=1),
+                              data="3d")
+                f3[name] = {"ms_per_step": o["ms_per_step"], "value": o["body_updates_per_s"], "roofline_frac": o["roofline"]["frac"],
+                            "executed_per_interaction": o["roofline"]["executed_per_interaction"]}
+            line["force_3d"] = f3
+        except Exception as e:  # pragma: no cover
+            line["force_3d"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("NB_FORCE_3D", None)
+            nb.reload_env()
+
+        # the boids controller (update_instance_boids, main.rs:443-526), same set and sharding
+        leg["name"] = "boids_controller"
+        try:
+            sc = nb.ShardedScene(pos, vel)
+            for _ in range(2):
+                sc.step_boids()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            bsteps = max(2, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(bsteps):
+                sc.step_boids()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
+            if world > 1:
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            line["boids_controller"] = {"metric": "body-updates/s, update_instance_boids (bit-exact)",
+                                        "value": n * bsteps / float(bt.item()),
+                                        "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
+        except Exception as e:  # pragma: no cover
+            line["boids_controller"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        leg["name"] = "cpu_baseline"
         import oracle  # cpu_baseline leg: the oracle is timed here, never used by the product path
 
-        cores = oracle.ncores()
+        lim = oracle.cpu_limits()
+        threads = lim["threads"]
+        # how many cores' worth of work the threads really deliver: one thread against all of them on a small set
+        ps, vs = pos[:32768], vel[:32768]
+        oracle.run(ps[:2048], vs[:2048], 1, threads=threads)  # page the library in
         t0 = time.perf_counter()
-        oracle.run(pos, vel, 1, threads=cores)
+        oracle.run(ps, vs, 1, threads=1)
+        t_one = time.perf_counter() - t0
+        thr0 = oracle.throttled_usec()
+        t0 = time.perf_counter()
+        oracle.run(ps, vs, 1, threads=threads)
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oracle.run(pos, vel, 1, threads=threads)
         dt = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": n / dt, "unit": "body-updates/s", "cores": cores, "kind": "port",
-                                "sample": f"1 full step of the same N={n} workload ({n * n:.3e} interactions), all host cores, "
+        throttled = oracle.throttled_usec() - thr0
+        line["cpu_baseline"] = {"value": n / dt, "unit": "body-updates/s", "cores": threads, "kind": "port",
+                                "sample": f"1 full step of the same N={n} workload ({n * n:.3e} interactions) on {threads} threads, "
                                           "C restatement of src/main.rs:404-441 (-O2 -ffp-contract=off)",
-                                "seconds": dt}
+                                "seconds": dt, "threads": threads, "affinity_cpus": lim["affinity"],
+                                "cgroup_quota_cores": lim["cgroup_quota_cores"],
+                                "effective_cores": t_one / t_all if t_all > 0 else None,
+                                "one_core_interactions_per_s": 32768.0 * 32768.0 / t_one,
+                                "interactions_per_s_per_thread": float(n) * n / dt / threads,
+                                "throttled_usec_during_run": throttled,
+                                "calibration": f"N=32768, one step: 1 thread {t_one:.3f} s, {threads} threads {t_all:.3f} s"}
     watchdog.cancel()
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -191,8 +191,13 @@ int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, u
 int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
 int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
 
+/* Diagnostic: the fp32 rate the vector ALU of THIS device sustains at the clock it holds under load -- a stream of
+ * independent v_fma_f32 on every SIMD (8 waves each) for about `seconds` (<= 2) -- in TFLOP/s (2 flop per lane-op).
+ * bench.py prints it beside the spec peak its roofline fraction is quoted against. */
+int nb_selftest_fma_rate(double seconds, double *tflops);
+
 /* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
- * NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
+ * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
  * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_SHARD_RCCL_SOLO) are read ONCE per process, at first use; no launch
  * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
  * and shards keep the launch shape chosen when they were created. */
@@ -215,6 +220,17 @@ size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t coun
  * pos_out must not alias pos_in. */
 int nb_launch_step(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
                    void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream);
+
+/* A FAST step in two phases, so that the exchange of a multi-GPU job can overlap with compute (SURVEY.md section 8e,
+ * "Overlap"): NB_PHASE_RANGE folds records [j_lo, j_hi) of pos_in only -- e.g. this rank's own slot of the snapshot, which
+ * is in place before the all-gather of the other slots has landed -- into `scratch`; NB_PHASE_REST folds the rest of the
+ * set, adds every partial sum in a fixed order and integrates (main.rs:434-436).  Both calls take the same arguments; the
+ * order of the additions differs from a one-call step (legal in FAST only: STRICT keeps the reference's j = 0..N-1 order
+ * and returns NB_ERR_UNSUPPORTED here).  scratch: nb_scratch_bytes_phased() bytes, untouched between the two calls. */
+enum { NB_PHASE_RANGE = 0, NB_PHASE_REST = 1 };
+size_t nb_scratch_bytes_phased(const nb_params *params, uint32_t n_total, uint32_t count, uint32_t j_lo, uint32_t j_hi);
+int nb_launch_step_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, uint32_t j_lo, uint32_t j_hi,
+                         int phase, const void *pos_in, void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream);
 
 /* One boids step (main.rs:443-526) for bodies [first, first+count) of a set of n_total:
  *   pos_in, vel_in    n_total records each: the snapshots old_positions / old_velocities (main.rs:459-460), read only

@@ -26,6 +26,8 @@ NB_ERR_UNSUPPORTED = -6
 
 NB_MODE_STRICT = 0
 NB_MODE_FAST = 1
+NB_PHASE_RANGE = 0
+NB_PHASE_REST = 1
 
 _STATUS_NAMES = {
     NB_ERR_INVALID: "NB_ERR_INVALID",
@@ -92,12 +94,19 @@ PROTOTYPES = {
     "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
     "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
+    "nb_selftest_fma_rate": (c_int, [ctypes.c_double, POINTER(ctypes.c_double)]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),
     "nb_launch_step": (
         c_int,
         [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "nb_scratch_bytes_phased": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_uint32]),
+    "nb_launch_step_phase": (
+        c_int,
+        [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+         c_void_p],
     ),
     "nb_launch_status": (c_int, [c_void_p]),
     "nb_debug_reload_env": (c_int, []),
@@ -169,6 +178,20 @@ def load() -> ctypes.CDLL:
         raise ImportError(f"libnenbody_hip.so ABI {got} != binding ABI {NB_ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def kernel_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the kernel and host sources of the library, in name order: stamps measurements
+    (profiles/hbm_traffic.json) with the code they were taken from, so a stale profile is recognised."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for path in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def default_params(mode: int = NB_MODE_STRICT, tile: int = 0) -> NbParams:

@@ -24,8 +24,10 @@ namespace {
 
 thread_local std::string g_tls_error = "";
 
-// MI355X: 256 CUs x 4 SIMDs.  FAST launches aim at 16 waves per SIMD's worth of work items: about twice what
-// is resident at once, which evens out the tail (measured: profiles/r01_first/sweep_fast.log).
+// MI355X: 256 CUs x 4 SIMDs.  FAST launches aim at 16 waves per SIMD's worth of work items: four times what is resident at
+// once (4 bodies per lane: 120 registers, 4 waves per SIMD).  Measured at N = 131 072 (profiles/r02/fast_forms.log): with
+// exactly one resident round (512 workgroups of 8 waves) the step takes 2.80 ms, with two rounds 2.62, with four 2.53 --
+// workgroups that all start together finish when the slowest CU does, later rounds go to whoever is free.
 constexpr uint32_t kTargetWaves = 16384;
 constexpr uint32_t kMaxSlices = 64;
 
@@ -40,7 +42,7 @@ struct Knob {
     bool on() const { return set && v != 0; }
 };
 struct DebugOverrides {
-    Knob tile, fast_ib, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
+    Knob tile, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
         strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
@@ -64,6 +66,8 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     DebugOverrides *d = new DebugOverrides();  // never freed: a handful per process at most (one, outside the test suite)
     d->tile = read_knob("NB_TILE");
     d->fast_ib = read_knob("NB_FAST_IB");
+    d->fast_groups = read_knob("NB_FAST_GROUPS");
+    d->fast_waves = read_knob("NB_FAST_WAVES");
     d->fast_slices = read_knob("NB_FAST_SLICES");
     d->fast_no_share = read_knob("NB_FAST_NO_SHARE");
     d->strict_force_ieee = read_knob("NB_STRICT_FORCE_IEEE");
@@ -101,8 +105,10 @@ bool valid_tile(uint32_t t) { return t == 256 || t == 512 || t == 1024; }
 struct Plan {
     uint32_t tile;
     uint32_t ib;      // FAST: bodies per thread
-    uint32_t slices;  // FAST: blockIdx.y slices of the j range
-    uint32_t j_chunk;
+    uint32_t waves;   // FAST: 0 = workgroup-tile form; else the barrier-free form with this many waves per workgroup (= groups)
+    uint32_t groups;  // FAST: 256-lane groups per workgroup, each folding its own j chunk (combined in LDS)
+    uint32_t slices;  // FAST: blockIdx.y slices of the j range (combined through memory)
+    uint32_t j_chunk; // FAST: records per chunk (groups * slices chunks cover the set)
     uint32_t lo_bits, hi_bits, force_ieee;  // STRICT guard
     int guard_a, guard_b, guard_g, guard_c; // its exponents: coordinates in {0} U [2^a, 2^b], |G| in [2^g, 2^(g+1)), bias in [2^c, 2^(c+1))
     uint32_t force_3d;                      // 2 = never take the planar shortcut (NB_FORCE_3D=1: tests, measurements)
@@ -122,6 +128,57 @@ int floor_log2f(float x)
     return e - 1;
 }
 
+// FAST: bodies per thread; two or four also let the thread's pairs share reciprocals
+uint32_t fast_bodies_per_lane(uint32_t n_total, uint32_t count)
+{
+    // by the size of the launch, in pairs (measured, profiles/r02/fast_forms.log): 16 384 of 131 072 bodies: 4 (0.340 ms
+    // against 0.360 with 2); standalone sets of 32 768 and 16 384: 2 (0.184 against 0.207 with 4); 8 192 and below: 1
+    const uint64_t pairs = (uint64_t)n_total * count;
+    uint32_t ib = overrides().fast_ib.or_else(pairs >= (1ull << 31) ? 4u : pairs >= (1ull << 27) ? 2u : 1u);
+    return (ib == 1 || ib == 2 || ib == 4) ? ib : 1u;
+}
+
+// FAST: 0 = the workgroup-tile form (step_fast_kernel), else waves per workgroup of the barrier-free form (1, 4, 8 or 16)
+uint32_t fast_wave_form()
+{
+    const uint32_t w = overrides().fast_waves.or_else(8u);  // NB_FAST_WAVES=0: the workgroup-tile form
+    return (w == 1 || w == 4 || w == 8 || w == 16) ? w : 0u;
+}
+
+// FAST: how a fold over `n_fold` records is split for `count` bodies at `ib` bodies per lane: `groups` chunks inside a
+// workgroup (combined in LDS) times `slices` across workgroups (combined through memory by integrate_partials_kernel),
+// `chunk` records each (a multiple of the tile).  The split aims at kTargetWaves waves in all.
+// `waves` != 0 selects the barrier-free form (step_fast_wave_kernel): a workgroup is `waves` waves that share 64*ib bodies
+// and fold one chunk each; then *groups = waves.
+void fast_split(uint32_t n_fold, uint32_t count, uint32_t ib, uint32_t waves, uint32_t *tile, uint32_t *groups, uint32_t *slices,
+                uint32_t *chunk)
+{
+    const DebugOverrides &dbg = overrides();
+    if (waves && *tile == 1024u) *tile = 512u;  // the wave form stages a whole tile per wave: 256 or 512 records
+    if (waves && *tile == 512u && ib == 1) *tile = 256u;
+    const uint32_t bodies = waves ? 64u * ib : 256u * ib, chunk_waves = waves ? 1u : 4u;
+    const uint32_t blocks = (count + bodies - 1u) / bodies;
+    const uint32_t max_by_tiles = std::max(1u, (n_fold + *tile - 1u) / *tile);
+    uint32_t split = (kTargetWaves + blocks * chunk_waves - 1u) / (blocks * chunk_waves);
+    if (split > max_by_tiles) split = max_by_tiles;
+    if (split < 1) split = 1;
+    uint32_t g = waves ? waves : dbg.fast_groups.or_else(split >= 4u ? 4u : split >= 2u ? 2u : 1u);
+    if (!waves && g != 1 && g != 2 && g != 4) g = 1;
+    if (!waves && *tile == 1024u) g = 1;  // groups are built for tiles of 256 and 512 records (4 x 2 x 1024 records = 128 KB of LDS)
+    uint32_t sl = dbg.fast_slices.or_else((split + g - 1u) / g);
+    if (sl > kMaxSlices) sl = kMaxSlices;
+    if (sl < 1) sl = 1;
+    uint32_t chunks = sl * g;
+    if (chunks > max_by_tiles) chunks = max_by_tiles;
+    uint32_t c = (std::max(n_fold, 1u) + chunks - 1u) / chunks;
+    c = ((c + *tile - 1u) / *tile) * *tile;
+    chunks = (std::max(n_fold, 1u) + c - 1u) / c;   // drop empty chunks ...
+    sl = (chunks + g - 1u) / g;                     // ... and the slices made of them
+    *groups = g;
+    *slices = sl;
+    *chunk = c;
+}
+
 // Launch shape + STRICT guard range for (params, n_total, count).  Pure host arithmetic.
 int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, std::string *err)
 {
@@ -133,33 +190,28 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         *err = "nb: params.mode must be NB_MODE_STRICT or NB_MODE_FAST";
         return NB_ERR_INVALID;
     }
+    if (n_total > 0x80000000u) {  // the kernels index records and tiles in 32 bits with headroom for padding
+        *err = "nb: sets of more than 2^31 bodies are not supported";
+        return NB_ERR_UNSUPPORTED;
+    }
     const DebugOverrides &dbg = overrides();
     Plan pl{};
     pl.tile = p.tile;
-    if (pl.tile == 0) pl.tile = dbg.tile.or_else((p.mode == NB_MODE_STRICT) ? 1024u : 512u);
+    // FAST: the barrier-free form stages a whole tile per wave (256 records: 4 per lane, 120 registers at 4 bodies per lane;
+    // 512 would take 142 and cost a wave per SIMD); the workgroup-tile form shares tiles of 512
+    if (pl.tile == 0) pl.tile = dbg.tile.or_else((p.mode == NB_MODE_STRICT) ? 1024u : fast_wave_form() ? 256u : 512u);
     if (!valid_tile(pl.tile)) {
         *err = "nb: params.tile must be 0, 256, 512 or 1024";
         return NB_ERR_INVALID;
     }
     pl.ib = 1;
+    pl.groups = 1;
     pl.slices = 1;
     pl.j_chunk = n_total;
     if (p.mode == NB_MODE_FAST) {
-        // bodies per thread; two or four also let the thread's pairs share reciprocals (measured against all 131 072 bodies:
-        // 131 072 / 65 536 / 32 768 bodies: 4 is fastest; 16 384: 2 -- 0.361 ms against 0.373 (1) and 0.375 (4))
-        pl.ib = dbg.fast_ib.or_else((count >= 32768u) ? 4u : (count >= 16384u) ? 2u : 1u);  // (standalone sets of 8 192: 1 is fastest)
-        if (pl.ib != 1 && pl.ib != 2 && pl.ib != 4) pl.ib = 1;
-        const uint32_t blocks = (count + 256u * pl.ib - 1u) / (256u * pl.ib);
-        uint32_t slices = dbg.fast_slices.or_else((kTargetWaves + blocks * 4u - 1u) / (blocks * 4u));
-        const uint32_t max_by_tiles = (n_total + pl.tile - 1u) / pl.tile;
-        if (slices > max_by_tiles) slices = max_by_tiles;
-        if (slices > kMaxSlices) slices = kMaxSlices;
-        if (slices < 1) slices = 1;
-        uint32_t chunk = (n_total + slices - 1u) / slices;
-        chunk = ((chunk + pl.tile - 1u) / pl.tile) * pl.tile;
-        slices = (n_total + chunk - 1u) / chunk;  // drop empty slices
-        pl.slices = slices;
-        pl.j_chunk = chunk;
+        pl.ib = fast_bodies_per_lane(n_total, count);
+        pl.waves = fast_wave_form();
+        fast_split(n_total, count, pl.ib, pl.waves, &pl.tile, &pl.groups, &pl.slices, &pl.j_chunk);
     }
     // STRICT: magnitude range {0} U [2^a, 2^b] of coordinates for which d, n = dx*G, q = n/d and the
     // ladder's residuals are all normal binary32 with headroom, so that v_div_scale/v_div_fixup would be
@@ -382,6 +434,10 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.j_chunk = pl.j_chunk;
     a.no_packed = pl.no_packed;
     a.spin_budget = pl.spin_budget;
+    a.j_count = n_total;  // the whole set: no base, no hole
+    a.j_base = 0;
+    a.hole_lo = 0xffffffffu;
+    a.hole_len = 0;
     uint32_t *status = nullptr;
     if (p.mode == NB_MODE_STRICT && pl.bc) {
         int rc = sw ? status_word_for_launch(sw, err) : device_status_word(&status, err);
@@ -391,7 +447,8 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, status, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
-                                              : nbk::launch_fast(a, pl.tile, pl.ib, pl.slices, stream);
+                                              : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
+                                                         : nbk::launch_fast(a, pl.tile, pl.ib, pl.groups, pl.slices, stream);
     if (e != hipSuccess) {
         *err = std::string("nb: kernel launch failed: ") + hipGetErrorString(e);
         return NB_ERR_HIP;
@@ -1191,6 +1248,51 @@ NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
     return NB_OK;
 }
 
+NB_EXPORT int nb_selftest_fma_rate(double seconds, double *tflops)
+{
+    if (!tflops || !(seconds > 0.0) || seconds > 2.0) {
+        g_tls_error = "nb_selftest_fma_rate: need tflops != NULL and 0 < seconds <= 2";
+        return NB_ERR_INVALID;
+    }
+    int rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&sink, 64);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const uint32_t blocks = (uint32_t)cus * 8u;  // 256 lanes = one wave per SIMD each: 8 waves per SIMD
+    auto timed = [&](uint32_t trips, float *ms) {
+        hipError_t x = hipEventRecord(e0, nullptr);
+        if (x == hipSuccess) x = nbk::launch_fma_stream(blocks, trips, sink, nullptr);
+        if (x == hipSuccess) x = hipEventRecord(e1, nullptr);
+        if (x == hipSuccess) x = hipEventSynchronize(e1);
+        if (x == hipSuccess) x = hipEventElapsedTime(ms, e0, e1);
+        return x;
+    };
+    float ms = 0.f;
+    uint32_t trips = 2000;
+    if (e == hipSuccess) e = timed(trips, &ms);  // warm-up + calibration (~ 1 ms)
+    if (e == hipSuccess && ms > 0.f) {
+        const double want = seconds * 1e3 / (double)ms * (double)trips;
+        trips = (uint32_t)std::min(std::max(want, 1000.0), 4.0e8);
+        e = timed(trips, &ms);
+    }
+    if (sink) (void)hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess || !(ms > 0.f)) {
+        g_tls_error = std::string("nb_selftest_fma_rate: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    const double flop = 2.0 * 64.0 * (double)trips * 256.0 * (double)blocks;
+    *tflops = flop / ((double)ms * 1e-3) / 1e12;
+    return NB_OK;
+}
+
 // ---- launch API -----------------------------------------------------------------------------------------
 
 NB_EXPORT size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count)
@@ -1249,6 +1351,124 @@ NB_EXPORT int nb_launch_status(void *stream)
         return NB_ERR_HIP;
     }
     return check_device_status(&g_tls_error);
+}
+
+// ---- a FAST step in two phases ("Overlap") -------------------------------------------------
+namespace {
+struct PhasePlan {
+    Plan base;                 // tile, ib, the sharing verdict, force_3d ...
+    uint32_t len[2];           // records folded by phase 0 (the range) and phase 1 (the rest)
+    uint32_t groups[2], slices[2], chunk[2];
+};
+
+int make_phase_plan(const nb_params &p, uint32_t n_total, uint32_t count, uint32_t j_lo, uint32_t j_hi, PhasePlan *out, std::string *err)
+{
+    if (p.mode != NB_MODE_FAST) {
+        *err = "nb: a step in phases is FAST only: the reference's sum runs j = 0..N-1 in order, and STRICT keeps that order";
+        return NB_ERR_UNSUPPORTED;
+    }
+    if (j_lo > j_hi || j_hi > n_total) {
+        *err = "nb: need j_lo <= j_hi <= n_total";
+        return NB_ERR_INVALID;
+    }
+    int rc = make_plan(p, n_total, count, &out->base, err);
+    if (rc != NB_OK) return rc;
+    out->len[0] = j_hi - j_lo;
+    out->len[1] = n_total - out->len[0];
+    for (int ph = 0; ph < 2; ++ph) {
+        uint32_t tile = out->base.tile;
+        fast_split(out->len[ph], count, out->base.ib, out->base.waves, &tile, &out->groups[ph], &out->slices[ph], &out->chunk[ph]);
+    }
+    return NB_OK;
+}
+}  // namespace
+
+NB_EXPORT size_t nb_scratch_bytes_phased(const nb_params *params, uint32_t n_total, uint32_t count, uint32_t j_lo, uint32_t j_hi)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    PhasePlan pp;
+    std::string err;
+    if (make_phase_plan(p, n_total, count, j_lo, j_hi, &pp, &err) != NB_OK) return 0;
+    return (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4);
+}
+
+NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, uint32_t j_lo,
+                                   uint32_t j_hi, int phase, const void *pos_in, void *pos_out, void *vel, void *scratch,
+                                   size_t scratch_bytes, void *stream)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    if (!pos_in || !pos_out || !vel || pos_in == pos_out || !scratch || (phase != NB_PHASE_RANGE && phase != NB_PHASE_REST)) {
+        g_tls_error = "nb_launch_step_phase: pos_in, pos_out, vel, scratch must be non-null, pos_out must not alias pos_in, phase is "
+                      "NB_PHASE_RANGE or NB_PHASE_REST";
+        return NB_ERR_INVALID;
+    }
+    if ((uint64_t)first + (uint64_t)count > (uint64_t)n_total) {
+        g_tls_error = "nb_launch_step_phase: [first, first+count) exceeds n_total";
+        return NB_ERR_INVALID;
+    }
+    PhasePlan pp;
+    int rc = make_phase_plan(p, n_total, count, j_lo, j_hi, &pp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (scratch_bytes < (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4)) {
+        g_tls_error = "nb_launch_step_phase: scratch smaller than nb_scratch_bytes_phased()";
+        return NB_ERR_INVALID;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    const Plan &pl = pp.base;
+    nbk::StepArgs a{};
+    a.pos_in = (const float4 *)pos_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel = (float4 *)vel;
+    a.partial = (float4 *)scratch;
+    a.n_total = n_total;
+    a.first = first;
+    a.count = count;
+    a.dt = p.dt;
+    a.G = p.G;
+    a.bias = p.bias;
+    a.force_ieee = pl.force_ieee;
+    a.force_3d = pl.force_3d;
+    a.always_partial = 1;
+    hipError_t e = hipSuccess;
+    if (phase == NB_PHASE_RANGE) {  // records [j_lo, j_hi) -> partial rows [0, slices[0])
+        a.j_count = pp.len[0];
+        a.j_base = j_lo;
+        a.hole_lo = 0xffffffffu;
+        a.hole_len = 0;
+        a.j_chunk = pp.chunk[0];
+        a.partial_row0 = 0;
+        if (pp.len[0])
+            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[0], (hipStream_t)stream)
+                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[0], pp.slices[0], (hipStream_t)stream);
+        else e = hipMemsetAsync(scratch, 0, (size_t)pp.slices[0] * count * sizeof(float4), (hipStream_t)stream);
+    } else {  // the set without [j_lo, j_hi) -> rows [slices[0], slices[0] + slices[1]), then every row in order + integrate
+        a.j_count = pp.len[1];
+        a.j_base = 0;
+        a.hole_lo = j_lo;
+        a.hole_len = pp.len[0];
+        a.j_chunk = pp.chunk[1];
+        a.partial_row0 = pp.slices[0];
+        if (pp.len[1])
+            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[1], (hipStream_t)stream)
+                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[1], pp.slices[1], (hipStream_t)stream);
+        else e = hipMemsetAsync((char *)scratch + (size_t)pp.slices[0] * count * sizeof(float4), 0,
+                                (size_t)pp.slices[1] * count * sizeof(float4), (hipStream_t)stream);
+        if (e == hipSuccess) e = nbk::launch_integrate_partials(a, pp.slices[0] + pp.slices[1], (hipStream_t)stream);
+    }
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_launch_step_phase: kernel launch failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
 }
 
 NB_EXPORT int nb_debug_reload_env(void)

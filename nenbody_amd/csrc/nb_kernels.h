@@ -16,9 +16,15 @@ struct StepArgs {
     uint32_t lo_bits, hi_bits;  // STRICT: bit patterns of the magnitude range where the unscaled divide ladder is exact
     uint32_t force_ieee;        // STRICT: 1 = always take the IEEE '/' path (parameters outside the proven range; tests)
     uint32_t force_3d;          // 2 (= kFlagNonPlanar) = never take the planar (z == 0) shortcut (tests, measurements)
-    uint32_t j_chunk;           // FAST: records per blockIdx.y slice, a multiple of the tile
+    uint32_t j_chunk;           // FAST: records per j chunk (one per 256-lane group per blockIdx.y slice), a multiple of the tile
     uint32_t no_packed;         // STRICT: 1 = planar tiles take the component-packed fold instead of the j-packed one (tests, measurements)
     uint32_t spin_budget;       // STRICT block chain: polls per wait before a wave gives up; 0 = the default (tests set a tiny one)
+    // FAST, a step in two phases (nb_launch_step_phase): the fold runs over j_count VIRTUAL records, virtual index v being
+    // record  j = v + j_base, plus hole_len if that is >= hole_lo  -- a contiguous range of the set, or the set without one.
+    // A whole-set launch has j_base = 0, hole_len = 0, j_count = n_total.
+    uint32_t j_count, j_base, hole_lo, hole_len;
+    uint32_t partial_row0;      // FAST: first row of a.partial this launch writes
+    uint32_t always_partial;    // FAST: 1 = write partial sums even when gridDim.y == 1 (a later launch integrates)
 };
 
 // Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
@@ -43,7 +49,10 @@ hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s
 // `status`: a device word the kernel ORs 1 into when a wave gave up waiting (outputs poisoned): the host's sticky error
 hipError_t launch_strict_bc(const StepArgs &a, void *scratch, uint32_t *status, hipStream_t s);
 size_t strict_bc_scratch_bytes(uint32_t n_total);
-hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t slices, hipStream_t s);
+hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t groups, uint32_t slices, hipStream_t s);
+hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t waves, uint32_t slices, hipStream_t s);
+// the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
+hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
 hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,
                           hipStream_t s);
@@ -55,6 +64,8 @@ hipError_t launch_ladder_exhaustive(uint32_t first_md, uint32_t count_md, bool c
                                     hipStream_t s);
 // v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for all 2^23 significands m and k in [k_lo, k_hi]
 hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations, hipStream_t s);
+// `blocks` workgroups of 256 lanes each issue trips * 64 independent v_fma_f32 per lane
+hipError_t launch_fma_stream(uint32_t blocks, uint32_t trips, float *sink, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

@@ -58,6 +58,17 @@ class HipBackend:
         check(self.lib.nb_launch_step(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
                                       vel.data_ptr(), sp, sb, stream))
 
+    def scratch_bytes_phased(self, params: NbParams, n_total: int, count: int, j_lo: int, j_hi: int) -> int:
+        return int(self.lib.nb_scratch_bytes_phased(ctypes.byref(params), n_total, count, j_lo, j_hi))
+
+    def step_phase(self, params, n_total, first, count, j_lo, j_hi, phase, pos_in, pos_out, vel, scratch) -> None:
+        """FAST only: ``nb_launch_step_phase`` -- phase 0 folds records [j_lo, j_hi), phase 1 the rest and integrates."""
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        check(self.lib.nb_launch_step_phase(ctypes.byref(params), n_total, first, count, j_lo, j_hi, phase, pos_in.data_ptr(),
+                                            pos_out.data_ptr(), vel.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+
     def instances(self, count, pos, vel, inst) -> None:
         import torch
 
@@ -81,7 +92,7 @@ class ShardedScene:
     """
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, device=None, group=None,
-                 backend=None, rank: Optional[int] = None, world: Optional[int] = None):
+                 backend=None, rank: Optional[int] = None, world: Optional[int] = None, overlap: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -119,7 +130,12 @@ class ShardedScene:
         if self.count:
             vrec[: self.count, :3] = torch.from_numpy(vel[self.first:self.first + self.count])
         self.vel = vrec.to(self.device)
-        sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
+        self.overlap = bool(overlap) and self.params.mode == _lib.NB_MODE_FAST and world > 1
+        self._pending = None     # the exchange in flight (overlap): a torch.distributed work handle, or None
+        if self.overlap:
+            sb = self.backend.scratch_bytes_phased(self.params, self.n, self.count, self.first, self.first + self.count) if self.count else 0
+        else:
+            sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
         self.scratch = torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None
         self.cur = 0
         self.steps_done = 0
@@ -127,12 +143,12 @@ class ShardedScene:
         self.velfull_valid = False
 
     # -- the exchange: every rank contributes its slot of `buf` and receives the others -----------------------
-    def _all_gather_slots(self, buf) -> None:
+    def _all_gather_slots(self, buf, async_op: bool = False):
         lo = self.rank * self.slot
         mine = buf[lo:lo + self.slot]
         if self.dist.get_backend(self.group) == "nccl":
             # RCCL, in place: the send buffer is this rank's slot of the receive buffer
-            self.dist.all_gather_into_tensor(buf, mine, group=self.group)
+            return self.dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op)
         elif buf.device.type == "cpu":
             self.dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
         else:
@@ -140,11 +156,19 @@ class ShardedScene:
             full = self.torch.empty(buf.shape, dtype=buf.dtype)
             self.dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
             buf.copy_(full)
+        return None  # these paths complete before returning
+
+    def _wait_pending(self) -> None:
+        """overlap: make the current stream wait for the exchange in flight (no host wait with RCCL)"""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
 
     # -- boids: update_instance_boids (main.rs:443-526) reads every old velocity, so velocities are replicated and
     #    gathered like positions ----------------------------------------------------------------------------------
     def step_boids(self, params=None) -> None:
         torch = self.torch
+        self._wait_pending()
         bp = params if params is not None else _lib.default_boids_params()
         lo = self.rank * self.slot
         if self.velfull is None:
@@ -172,10 +196,22 @@ class ShardedScene:
     # -- one step: local update, then the exchange ------------------------------------------------------
     def step(self) -> None:
         src, dst = self.pos[self.cur], self.pos[self.cur ^ 1]
-        if self.count:
-            self.backend.step(self.params, self.n, self.first, self.count, src, dst, self.vel, self.scratch)
-        if self.world > 1:
-            self._all_gather_slots(dst)
+        if self.overlap:
+            # src's other slots may still be landing; this rank's own slot of src was written by its own last step
+            lo, hi = self.first, self.first + self.count
+            if self.count:
+                self.backend.step_phase(self.params, self.n, self.first, self.count, lo, hi, _lib.NB_PHASE_RANGE, src, dst, self.vel,
+                                        self.scratch)
+            self._wait_pending()
+            if self.count:
+                self.backend.step_phase(self.params, self.n, self.first, self.count, lo, hi, _lib.NB_PHASE_REST, src, dst, self.vel,
+                                        self.scratch)
+            self._pending = self._all_gather_slots(dst, async_op=True)
+        else:
+            if self.count:
+                self.backend.step(self.params, self.n, self.first, self.count, src, dst, self.vel, self.scratch)
+            if self.world > 1:
+                self._all_gather_slots(dst)
         self.velfull_valid = False  # the velocity replica (boids only) no longer matches the local velocities
         self.cur ^= 1
         self.steps_done += 1
@@ -186,6 +222,7 @@ class ShardedScene:
 
     def sync(self) -> None:
         """Wait for the queued steps; raises NbError (NB_ERR_STATE) if a kernel reported a failure (``nb_launch_status``)."""
+        self._wait_pending()
         if self.device.type == "cuda":
             self.torch.cuda.synchronize(self.device)
             if self.backend.name == "hip":
@@ -194,6 +231,7 @@ class ShardedScene:
     # -- state access -------------------------------------------------------------------------------------
     def positions(self) -> np.ndarray:
         """All n positions (every rank holds the replica), shape (n, 3)."""
+        self._wait_pending()
         return self.pos[self.cur][: self.n, :3].cpu().numpy().copy()
 
     def local_velocities(self) -> np.ndarray:
@@ -213,6 +251,7 @@ class ShardedScene:
 
     def local_instances(self) -> np.ndarray:
         """Model matrices (main.rs:437-439) of this rank's bodies, shape (count, 4, 4)."""
+        self._wait_pending()
         inst = self.torch.zeros((max(self.count, 1), 16), dtype=self.torch.float32, device=self.device)
         if self.count:
             mine = self.pos[self.cur][self.first:self.first + self.count]

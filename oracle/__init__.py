@@ -53,6 +53,8 @@ def load() -> ctypes.CDLL:
         lib.nbo_run.restype = i
         lib.nbo_run_f64.argtypes = [vp, vp, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         lib.nbo_run_f64.restype = i
+        lib.nbo_step_range_dv_f64.argtypes = [vp, vp, u32, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        lib.nbo_step_range_dv_f64.restype = None
         lib.nbo_cameras.argtypes = [vp, vp, vp, vp, vp, u32]
         lib.nbo_cameras.restype = None
         lib.nbo_random_step_range.argtypes = [vp, vp, vp, u32, u32, u64, u64]
@@ -155,6 +157,17 @@ def run_f64(pos, vel, k: int, dt=0.1, g=0.001, bias=0.0000001):
     rc = load().nbo_run_f64(p.ctypes.data, v.ctypes.data, len(p), k, dt, g, bias)
     assert rc == 0
     return p, v
+
+
+def step_range_dv_f64(old_pos, first: int, count: int, dt=0.1, g=0.001, bias=0.0000001):
+    """One step's velocity change of bodies [first, first+count), accumulated in binary64 from the binary32 snapshot:
+    the yardstick for the rounding error of a binary32 sum (the reference's included).  Note the binary64 constants are
+    the decimal literals of main.rs:411-413, not the binary32 roundings of them: callers compare at tolerances far above
+    that difference (1e-8 relative)."""
+    old = np.ascontiguousarray(old_pos, np.float32)
+    dv = np.empty((count, 3), np.float64)
+    load().nbo_step_range_dv_f64(old.ctypes.data, dv.ctypes.data, len(old), first, count, float(dt), float(g), float(bias))
+    return dv
 
 
 def boids_params() -> BoidsParams:

@@ -552,3 +552,28 @@ NBO_API int nbo_run_f64(double *pos3, double *vel3, uint32_t n, uint32_t k, doub
     free(old);
     return 0;
 }
+
+/* The same binary64 recurrence for bodies [first, first+count) of ONE step against a binary32 snapshot (each record
+ * widened exactly): the velocity change a_n*dt with ~1e-16 relative error per term, i.e. the yardstick against which the
+ * rounding error of the reference's own binary32 sum (and of any reassociated binary32 sum) is measured in the tests.
+ * dv3_out: 3*count doubles = the step's velocity change of each body. */
+NBO_API void nbo_step_range_dv_f64(const float *old_pos3, double *dv3_out, uint32_t n_total, uint32_t first, uint32_t count,
+                                   double dt, double G, double bias)
+{
+    for (uint32_t l = 0; l < count; ++l) {
+        const size_t b = (size_t)first + l;
+        const double px = old_pos3[3 * b], py = old_pos3[3 * b + 1], pz = old_pos3[3 * b + 2];
+        double sx = 0, sy = 0, sz = 0;
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const double vx = (double)old_pos3[3 * (size_t)i] - px, vy = (double)old_pos3[3 * (size_t)i + 1] - py,
+                         vz = (double)old_pos3[3 * (size_t)i + 2] - pz;
+            const double dist = ((vx * vx + vy * vy) + vz * vz) + bias;
+            sx = sx + (vx * G) / dist;
+            sy = sy + (vy * G) / dist;
+            sz = sz + (vz * G) / dist;
+        }
+        dv3_out[3 * (size_t)l] = sx * dt;
+        dv3_out[3 * (size_t)l + 1] = sy * dt;
+        dv3_out[3 * (size_t)l + 2] = sz * dt;
+    }
+}

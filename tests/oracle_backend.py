@@ -24,6 +24,31 @@ class OracleBackend:
         pos_out[first:first + count, 3] = 0
         vel[:count, :3] = torch.from_numpy(v_new)
 
+    # -- a FAST step in two phases (nb_launch_step_phase): the sums of records [j_lo, j_hi) first, the rest later --------
+    def scratch_bytes_phased(self, params, n_total, count, j_lo, j_hi):
+        return 16 * count
+
+    @staticmethod
+    def _partial(params, old, first, count, js):
+        """sum over records js of ((p_j - p_n) * G) / (|p_j - p_n|^2 + bias) for bodies [first, first+count): numpy binary32,
+        any order -- this backend tests the ORCHESTRATION (what is read when), FAST tolerances apply"""
+        d = old[js][None, :, :] - old[first:first + count][:, None, :]
+        r2 = (d * d).sum(axis=2, dtype=np.float32) + np.float32(params.bias)
+        return ((d * np.float32(params.G)) / r2[:, :, None]).sum(axis=1, dtype=np.float32)
+
+    def step_phase(self, params, n_total, first, count, j_lo, j_hi, phase, pos_in, pos_out, vel, scratch):
+        old = pos_in[:n_total, :3].contiguous().numpy()
+        part = scratch.view(torch.float32).reshape(count, 4)
+        if phase == 0:
+            part[:, :3] = torch.from_numpy(self._partial(params, old, first, count, np.arange(j_lo, j_hi)))
+            return
+        rest = np.concatenate([np.arange(0, j_lo), np.arange(j_hi, n_total)])
+        a = part[:, :3].numpy() + self._partial(params, old, first, count, rest)
+        v = vel[:count, :3].numpy() + a * np.float32(params.dt)
+        pos_out[first:first + count, :3] = torch.from_numpy(v + old[first:first + count])
+        pos_out[first:first + count, 3] = 0
+        vel[:count, :3] = torch.from_numpy(v)
+
     def instances(self, count, pos, vel, inst):
         m = oracle.instances(pos[:count, :3].contiguous().numpy(), vel[:count, :3].contiguous().numpy())
         inst[:count] = torch.from_numpy(m.reshape(count, 16))

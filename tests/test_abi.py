@@ -201,3 +201,86 @@ def test_shard_argument_contract_and_no_device(nb):
         nb.NativeShard(pos, vel)
     with pytest.raises(nb.NbError):   # no RCCL without a device either (NB_ERR_NO_DEVICE or NB_ERR_UNSUPPORTED if librccl is absent)
         nb.comm_id()
+
+
+def test_debug_overrides_are_read_once_and_reloaded_on_request(nb, monkeypatch):
+    """The NB_* kernel-form overrides are parsed once per process; nb_debug_reload_env() (which the test suite's monkeypatch
+    calls for NB_* names) makes the library read them again.  Pure host arithmetic: visible through nb_scratch_bytes."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    auto = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
+    os.environ["NB_FAST_SLICES"] = "3"          # behind the library's back: not seen ...
+    try:
+        assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == auto
+        assert lib.nb_debug_reload_env() == _lib.NB_OK  # ... until it is told to look
+        assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 3 * 16384 * 16
+    finally:
+        del os.environ["NB_FAST_SLICES"]
+        lib.nb_debug_reload_env()
+    assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == auto
+    monkeypatch.setenv("NB_FAST_SLICES", "1")   # the fixture reloads by itself
+    monkeypatch.setenv("NB_FAST_GROUPS", "4")
+    assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 0   # the j chunks meet in LDS: nothing through memory
+    strict = nb.default_params()
+    monkeypatch.setenv("NB_STRICT_BC", "0")
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 0
+    monkeypatch.setenv("NB_STRICT_BC", "1")
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072
+
+
+def test_plan_arithmetic_over_many_shapes(nb):
+    """make_plan is pure host arithmetic: walk it over ragged sizes, every mode and tile (this is what the sanitizer build
+    of the host code exercises: tests/test_abi_asan.py).  Scratch sizes must be consistent with the shape."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    for mode in (nb.NB_MODE_STRICT, nb.NB_MODE_FAST):
+        for tile in (0, 256, 512, 1024):
+            p = nb.default_params(mode=mode, tile=tile)
+            for n in (1, 2, 63, 64, 65, 255, 4095, 4096, 4097, 65535, 65536, 65537, 131072, 1 << 20, (1 << 24) + 5, 1 << 31, 0xffffffff):
+                for count in sorted({1, min(n, 64), min(n, 16384), max(1, n // 8), max(1, n // 2), n}):
+                    b = lib.nb_scratch_bytes(ctypes.byref(p), n, count)
+                    if n > 1 << 31:      # refused (32-bit record indices need headroom for padding): no plan, no scratch
+                        assert b == 0
+                    elif mode == nb.NB_MODE_FAST:
+                        assert b % (count * 16) == 0 and b // (count * 16) <= 64
+                    else:
+                        assert b in (0, 256 + 3 * 4 * ((n + 63) // 64 * 64))
+    # the repeated call of a rank: same shape, same answer (per-thread plan cache), and a different shape in between
+    fake_a, fake_b, fake_v = 0x1000, 0x2000, 0x3000
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    for _ in range(3):
+        assert lib.nb_launch_step(ctypes.byref(fast), 131072, 0, 16384, fake_a, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+        assert "scratch" in _lib.last_error()
+        assert lib.nb_launch_step(ctypes.byref(fast), 1 << 20, 131072, 131072, fake_a, fake_b, fake_v, None, 0, None) == _lib.NB_ERR_INVALID
+    # constants the STRICT ladder has no guarded range for still plan (they take the IEEE divide)
+    odd = nb.default_params()
+    for g, bias in ((0.0, 1e-7), (1e-3, 0.0), (float("inf"), 1e-7), (1e-3, float("nan")), (1e38, 1e-38), (1e-38, 1e38), (-1e-3, 1e-7)):
+        odd.G, odd.bias = g, bias
+        assert lib.nb_scratch_bytes(ctypes.byref(odd), 131072, 16384) == 256 + 3 * 4 * 131072
+
+
+def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    tf = ctypes.c_double()
+    assert lib.nb_selftest_fma_rate(0.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_fma_rate(0.05, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_fma_rate(5.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    bad = ctypes.c_uint64()
+    assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_rcp_scaling(5, 4, ctypes.byref(bad)) == _lib.NB_ERR_INVALID
+    if lib.nb_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    assert lib.nb_launch_status(None) == _lib.NB_ERR_NO_DEVICE
+    assert lib.nb_selftest_fma_rate(0.05, ctypes.byref(tf)) == _lib.NB_ERR_NO_DEVICE
+    # the boids drop-in pads the shorter snapshot on the host before it needs the device
+    pos, vel = nb.init_state(12)
+    with pytest.raises(nb.NbError) as ei:
+        nb.update_instance_boids(np.zeros((12, 4, 4), np.float32), pos, pos.copy(), vel[:5].copy(), vel[:5].copy())
+    assert ei.value.status == _lib.NB_ERR_NO_DEVICE
+    with pytest.raises(nb.NbError):
+        nb.update_instance_boids(np.zeros((12, 4, 4), np.float32), pos[:5].copy(), pos[:5].copy(), vel, vel.copy())

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, out_dir, boids=False):
+def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,8 +33,9 @@ def _worker(rank, world, port, n, k, out_dir, boids=False):
 
         pos, vel = oracle.init_state(n, seed=4321)
         pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
-        sc = nenbody_amd.ShardedScene(pos, vel, backend=OracleBackend(), device="cpu")
-        assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank]
+        params = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST) if overlap else None
+        sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap)
+        assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap
         if boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
             sc.step_boids()
             sc.step()
@@ -89,3 +90,24 @@ def test_sharded_boids_equals_unsharded(tmp_path, oracle, world, n, k):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert (got["pos"].view(np.uint32) == p_ref.view(np.uint32)).all()
         assert (got["vel"].view(np.uint32) == v_ref.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("world,n,k", [(2, 64, 5), (3, 50, 4), (3, 2, 3)])
+def test_sharded_fast_with_overlapped_exchange(tmp_path, oracle, world, n, k):
+    """overlap=True (FAST): each step folds this rank's own slot of the new snapshot first, then waits for the exchange of the
+    others, folds the rest and integrates (nb_launch_step_phase).  Every record of the snapshot must have been read after
+    it arrived: the run must match the unsharded run to FAST's tolerance on every rank (ranks with no bodies included).
+    With STRICT the flag is ignored: the reference's order of additions stays."""
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), False, True), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nenbody_amd
+    from oracle_backend import OracleBackend
+
+    sc = nenbody_amd.ShardedScene(pos, vel, backend=OracleBackend(), device="cpu", overlap=True)   # STRICT, world 1
+    assert not sc.overlap

@@ -362,6 +362,76 @@ def test_config5_size_one_million_bodies_sampled(nb, oracle):
     assert acc > 0
 
 
+# BASELINE configs 4 and 5: the launch shapes every rank of the 2-, 4- and 8-GPU jobs issues -- (first, count) of
+# nenbody_amd.dist.partition, first != 0 for all but rank 0, the library's own choice of kernel form, slices and bodies per
+# thread for that count -- run one after another on the one GPU and assembled into the step.
+_REF_STEP = {}
+
+
+def _unsharded_reference_step(nb, n, mode):
+    """one whole-set step on the GPU (STRICT and FAST), cached across the parametrised cases"""
+    key = (n, mode)
+    if key not in _REF_STEP:
+        pos, vel = nb.init_state(n, 1234)
+        with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
+            sc.step_n(1)
+            _REF_STEP[key] = sc.state()
+    return _REF_STEP[key]
+
+
+@pytest.mark.parametrize("n,world", [(131072, 2), (131072, 4), (131072, 8), (1 << 20, 2), (1 << 20, 4), (1 << 20, 8)],
+                         ids=lambda x: str(x))
+def test_every_rank_shape_of_configs_4_and_5_vs_oracle(nb, oracle, n, world):
+    pos, vel = nb.init_state(n, 1234)
+    parts = nb.partition(n, world)
+    assert all(c == n // world for _, c in parts) and [f for f, _ in parts][1] == n // world
+    # STRICT: all ranks' launches == the unsharded step, bit for bit, every body ...
+    p1, v1 = _unsharded_reference_step(nb, n, nb.NB_MODE_STRICT)
+    ps, vs = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(), 1)
+    assert_bits_equal(ps, p1, f"STRICT positions, {world} ranks vs 1")
+    assert_bits_equal(vs, v1, f"STRICT velocities, {world} ranks vs 1")
+    # ... and == the oracle on bodies of EVERY rank: first, last and six inside each range (>= 64 bodies at 8 ranks)
+    idx = np.unique(np.concatenate([np.concatenate([[f, f + c - 1], np.linspace(f + 1, f + c - 2, 6).astype(np.int64)])
+                                    for f, c in parts]))
+    v_ref = np.empty((len(idx), 3), np.float32)
+    for k, i in enumerate(idx):
+        p_ref, vr = oracle.step_range(pos, vel[i:i + 1], int(i), 1)
+        v_ref[k] = vr[0]
+        assert (bits(ps[i]) == bits(p_ref[0])).all() and (bits(vs[i]) == bits(vr[0])).all(), f"STRICT body {i}"
+    # FAST, the library's own slices / bodies per thread for this count: against the reference's arithmetic AND against
+    # the same sum carried in binary64.  The reference's sequential binary32 sum of n terms carries a rounding error of its
+    # own (~sqrt(n) half-ulps of a sum that is ~n*G/R); FAST's partial sums carry less.  So FAST is held to (a) the stated
+    # per-step tolerance against the oracle, widened at n = 2^20 to 1e-4 of the velocity change, and (b) -- the evidence
+    # for that widening -- being no further from the binary64 sum than the reference's own arithmetic is.
+    pf, vf = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(mode=nb.NB_MODE_FAST), 1)
+    pf1, vf1 = _unsharded_reference_step(nb, n, nb.NB_MODE_FAST)
+    c = [float(np.float32(x)) for x in (0.1, 0.001, 0.0000001)]
+    dv64 = np.concatenate([oracle.step_range_dv_f64(pos, int(i), 1, *c) for i in idx])
+    v_true = vel[idx].astype(np.float64) + dv64
+    scale = np.abs(dv64).max()
+    err_ref = np.abs(v_ref.astype(np.float64) - v_true).max(axis=1)
+    err_fast = np.abs(vf[idx].astype(np.float64) - v_true).max(axis=1)
+    ulp_v = float(np.spacing(np.float32(np.abs(v_true).max())))      # the final rounding of v = v + a*dt, common to both
+    msg = (f"n={n} ranks={world}: max |v - v64| / max|dv|: reference binary32 {err_ref.max() / scale:.2e}, FAST "
+           f"{err_fast.max() / scale:.2e}; max |FAST - reference| / max|dv| {np.abs(vf[idx] - v_ref).max() / scale:.2e}")
+    print(msg)
+    assert err_fast.max() <= err_ref.max() + ulp_v, msg
+    assert (err_fast <= err_ref + 2e-5 * scale + ulp_v).all(), msg
+    tol = 2e-5 if n <= 131072 else 1e-4
+    assert np.abs(vf[idx] - v_ref).max() <= tol * scale + ulp_v, msg
+    # sharding FAST changes the chunk boundaries, not the law: over ALL bodies the ranks' launches stay within tolerance of the
+    # whole-set launch.  A body with a neighbour at r ~ 1e-4 (there are a few among 2^20 bodies in a 200 x 200 box) has one
+    # term G*dt/r ~ 1 in its sum: every later addition then rounds at that magnitude, in the reference's sequential sum as
+    # in any other order, so two orders differ by ~1e-4 for such a body -- hence a bound on the bulk (99.9 %) at FAST's
+    # stated tolerance and a looser one on the worst body.
+    ulp_p = float(np.spacing(np.float32(np.abs(pf1).max())))          # the final rounding of p = v + p
+    dv_all = np.abs(vf - vf1).max(axis=1)
+    # (both are binary32 sums with their own rounding error -- a whole-set launch at 2^20 bodies does not split j at all and
+    # carries a sequential sum's error, like the reference -- so the two may differ by twice the tolerance against the oracle)
+    assert np.quantile(dv_all, 0.999) <= 2 * tol * scale + ulp_v and dv_all.max() <= 1e-3 * scale, msg + f"; all bodies: {dv_all.max():.2e}"
+    assert np.abs(pf - pf1).max() <= dv_all.max() + ulp_p, msg
+
+
 def test_fast_full_size_close_to_strict_and_shard_consistent(nb):
     n = 131072
     pos, vel = nb.init_state(n, 1234)
@@ -394,9 +464,14 @@ def test_fast_within_tolerance_of_oracle(nb, oracle, n, k, tol_r):
     assert dr < tol_r, f"max |dr| = {dr:.3e} after {k} steps"
 
 
-@pytest.mark.parametrize("ib,slices,tile", [(1, 1, 256), (2, 1, 512), (4, 1, 1024), (1, 4, 256), (2, 7, 512), (4, 64, 256)])
-def test_fast_every_launch_shape(nb, oracle, monkeypatch, ib, slices, tile):
+@pytest.mark.parametrize("ib,groups,slices,tile", [(1, 1, 1, 256), (2, 1, 1, 512), (4, 1, 1, 1024), (1, 1, 4, 256), (2, 1, 7, 512),
+                                                   (4, 1, 64, 256), (1, 2, 1, 256), (2, 2, 3, 512), (4, 2, 1, 256), (1, 4, 1, 512),
+                                                   (2, 4, 2, 256), (4, 4, 1, 512), (4, 4, 5, 256), (4, 4, 16, 512)])
+def test_fast_every_launch_shape(nb, oracle, monkeypatch, ib, groups, slices, tile):
+    """bodies per lane x 256-lane groups per workgroup (each folding its own j chunk, combined in LDS) x grid.y slices
+    (combined through memory) x tile: every built shape, ragged sizes included"""
     monkeypatch.setenv("NB_FAST_IB", str(ib))
+    monkeypatch.setenv("NB_FAST_GROUPS", str(groups))
     monkeypatch.setenv("NB_FAST_SLICES", str(slices))
     n = 5000
     pos, vel = state3d(oracle, n, seed=ib * 100 + slices)
@@ -407,6 +482,90 @@ def test_fast_every_launch_shape(nb, oracle, monkeypatch, ib, slices, tile):
     acc = np.abs(v_ref - vel).max()
     assert np.abs(v - v_ref).max() <= 2e-5 * acc + 1e-9
     assert np.abs(p - p_ref).max() <= 1e-5
+
+
+@pytest.mark.parametrize("ib,waves,slices,tile", [(1, 1, 1, 256), (1, 4, 3, 256), (1, 16, 1, 256), (2, 8, 1, 256), (2, 16, 2, 512), (4, 4, 5, 256),
+                                                  (4, 8, 1, 256), (4, 16, 1, 256), (4, 16, 2, 512), (2, 4, 64, 256)])
+def test_fast_wave_form_every_launch_shape(nb, oracle, monkeypatch, ib, waves, slices, tile):
+    """the barrier-free FAST form (step_fast_wave_kernel): `waves` waves per workgroup share 64*ib bodies, stage their own
+    tiles and fold one j chunk each; sums meet in LDS in wave order, grid.y slices through memory"""
+    monkeypatch.setenv("NB_FAST_IB", str(ib))
+    monkeypatch.setenv("NB_FAST_WAVES", str(waves))
+    monkeypatch.setenv("NB_FAST_SLICES", str(slices))
+    for n in (5000, 64 * ib, 777):
+        pos, vel = state3d(oracle, n, seed=ib * 100 + slices + waves)
+        if n == 777:
+            pos[:, 2] = 0          # the planar form of the fold
+            vel[:, 2] = 0
+        fast = nb.default_params(mode=nb.NB_MODE_FAST, tile=tile)
+        outs = []
+        for _ in range(2):
+            with nb.Scene(pos, vel, fast) as sc:
+                sc.step_n(2)
+                outs.append(sc.state())
+        assert_bits_equal(outs[0][0], outs[1][0], "run-to-run determinism")
+        assert_bits_equal(outs[0][1], outs[1][1], "run-to-run determinism (velocities)")
+        p, v = outs[0]
+        p_ref, v_ref = oracle.run(pos, vel, 2)
+        acc = np.abs(v_ref - vel).max()
+        assert np.abs(v - v_ref).max() <= 4e-5 * acc + float(np.spacing(np.abs(v_ref).max())), f"n={n}"
+        assert np.abs(p - p_ref).max() <= 2e-5, f"n={n}"
+
+
+@pytest.mark.parametrize("waves", [0, 8])
+@pytest.mark.parametrize("n,first,count,j_lo,j_hi", [(6000, 0, 6000, 0, 750), (6000, 1500, 750, 1500, 2250), (6000, 5250, 750, 5250, 6000),
+                                                     (5001, 1000, 333, 0, 0), (5001, 0, 5001, 0, 5001), (131072, 16384, 16384, 16384, 32768)])
+def test_fast_step_in_two_phases_equals_one_call(nb, oracle, monkeypatch, waves, n, first, count, j_lo, j_hi):
+    """nb_launch_step_phase: NB_PHASE_RANGE folds records [j_lo, j_hi) (a rank's own slot, present before the all-gather lands),
+    NB_PHASE_REST the rest of the set + every partial sum in a fixed order + the integration.  Same law, another order of
+    additions: within FAST's tolerance of the one-call step and of the oracle; deterministic; STRICT refuses."""
+    import torch
+
+    from nenbody_amd import _lib
+
+    if waves:
+        monkeypatch.setenv("NB_FAST_WAVES", str(waves))
+    lib = _lib.load()
+    pos, vel = state3d(oracle, n, seed=n + first)
+    dev = torch.device("cuda", 0)
+    cur = torch.zeros((n, 4), dtype=torch.float32)
+    cur[:, :3] = torch.from_numpy(pos)
+    cur = cur.to(dev)
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def phased():
+        nxt = torch.zeros_like(cur)
+        v = torch.zeros((count, 4), dtype=torch.float32)
+        v[:, :3] = torch.from_numpy(vel[first:first + count])
+        v = v.to(dev)
+        sb = lib.nb_scratch_bytes_phased(ctypes.byref(fast), n, count, j_lo, j_hi)
+        assert sb >= 2 * count * 16
+        scratch = torch.empty((sb,), dtype=torch.uint8, device=dev)
+        for phase in (_lib.NB_PHASE_RANGE, _lib.NB_PHASE_REST):
+            _lib.check(lib.nb_launch_step_phase(ctypes.byref(fast), n, first, count, j_lo, j_hi, phase, cur.data_ptr(), nxt.data_ptr(),
+                                               v.data_ptr(), scratch.data_ptr(), sb, stream))
+        torch.cuda.synchronize()
+        return nxt[first:first + count, :3].cpu().numpy(), v[:, :3].cpu().numpy()
+
+    p2, v2 = phased()
+    p2b, v2b = phased()
+    assert_bits_equal(p2, p2b, "run-to-run determinism")
+    assert_bits_equal(v2, v2b, "run-to-run determinism (velocities)")
+    idx = np.unique(np.concatenate([[0, count - 1], np.linspace(0, count - 1, 24).astype(np.int64)]))
+    scale = 0.0
+    for i in idx:
+        p_ref, v_ref = oracle.step_range(pos, vel[first + i:first + i + 1], int(first + i), 1)
+        scale = max(scale, float(np.abs(v_ref[0] - vel[first + i]).max()))
+    for i in idx:
+        p_ref, v_ref = oracle.step_range(pos, vel[first + i:first + i + 1], int(first + i), 1)
+        assert np.abs(v2[i] - v_ref[0]).max() <= 4e-5 * scale + 1e-9, f"body {first + i}"
+        assert np.abs(p2[i] - p_ref[0]).max() <= 4e-5 * scale + 1e-5, f"body {first + i}"
+    strict = nb.default_params()
+    assert lib.nb_scratch_bytes_phased(ctypes.byref(strict), n, count, j_lo, j_hi) == 0
+    rc = lib.nb_launch_step_phase(ctypes.byref(strict), n, first, count, j_lo, j_hi, 0, cur.data_ptr(), cur.data_ptr() + 16, cur.data_ptr(),
+                                  cur.data_ptr(), 1 << 30, stream)
+    assert rc == _lib.NB_ERR_UNSUPPORTED and "order" in _lib.last_error()
 
 
 def test_fast_shared_reciprocal_guard(nb, oracle, monkeypatch):
@@ -581,7 +740,7 @@ def test_instances_edge_cases(nb, oracle):
 # several ranks on the one GPU of this box (gloo, positions gathered through the host): the real multi-rank
 # control flow with the real HIP kernels.  RCCL itself needs one GPU per rank and is the driver's to run.
 # ---------------------------------------------------------------------------------------------------------
-def _rank_worker(rank, world, port, n, k, mode, out_dir):
+def _rank_worker(rank, world, port, n, k, mode, out_dir, overlap=False):
     import sys
 
     from conftest import ROOT
@@ -599,7 +758,8 @@ def _rank_worker(rank, world, port, n, k, mode, out_dir):
         torch.cuda.set_device(0)
         pos, vel = nenbody_amd.init_state(n, 99)
         pos[:, 2] = np.linspace(-50, 50, n, dtype=np.float32)
-        sc = nenbody_amd.ShardedScene(pos, vel, nenbody_amd.default_params(mode=mode))
+        sc = nenbody_amd.ShardedScene(pos, vel, nenbody_amd.default_params(mode=mode), overlap=overlap)
+        assert sc.overlap == (overlap and mode == nenbody_amd.NB_MODE_FAST)
         sc.step_n(k)
         sc.sync()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities())
@@ -625,6 +785,30 @@ def test_multirank_on_one_gpu_strict_equals_oracle(tmp_path, nb, oracle, world, 
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert_bits_equal(got["pos"], p_ref, f"rank {r} positions")
         assert_bits_equal(got["vel"], v_ref, f"rank {r} velocities")
+
+
+@pytest.mark.parametrize("world,n", [(2, 4096), (3, 1000), (3, 20000)])
+def test_multirank_on_one_gpu_fast_with_overlapped_exchange(tmp_path, nb, oracle, world, n):
+    """FAST with overlap=True, real kernels, 2-3 ranks sharing the GPU (gloo exchange): every step folds the rank's own slot
+    first (NB_PHASE_RANGE), then the rest after the exchange (NB_PHASE_REST).  Within FAST's tolerance of the oracle on every
+    rank.  (No performance claim: the overlap needs one GPU per rank and RCCL to show.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k = 3
+    mp.spawn(_rank_worker, args=(world, port, n, k, nb.NB_MODE_FAST, str(tmp_path), True), nprocs=world, join=True)
+    pos, vel = nb.init_state(n, 99)
+    pos[:, 2] = np.linspace(-50, 50, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    acc = np.abs(v_ref - vel).max()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.abs(got["vel"] - v_ref).max() <= 4e-5 * acc + 1e-9, f"rank {r}"
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5, f"rank {r}"
 
 
 def _rccl_world_of_one(rank, port, n, k, out_dir):

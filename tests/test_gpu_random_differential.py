@@ -91,6 +91,7 @@ def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
     n = int(rng.choice([64, 300, 1000, 2500, 4000]))
     monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
     monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
+    monkeypatch.setenv("NB_FAST_GROUPS", str(int(rng.choice([1, 2, 4]))))
     pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
     vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
     if case % 2 == 0:

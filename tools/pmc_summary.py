@@ -2,22 +2,31 @@
 """Summarise rocprofv3 --pmc passes (one directory per pass) into one table per kernel.
 
     python tools/pmc_summary.py gpurun_out/pmc > profiles/<round>/pmc_summary.txt
+    python tools/pmc_summary.py gpurun_out/pmc --json profiles/hbm_traffic.json --n 131072 --count 131072 --source profiles/<round>/
+
+--json writes the HBM bytes per launch of every kernel (no hand transcription), stamped with the sha of the kernel
+sources they were measured on; bench.py reports them as roofline.traffic and refuses a file with another stamp.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request
 for wide coalesced reads, so the read side is doubled before it is compared with a byte count
 (/opt/skills/guides/MI355X_MICROARCH.md, section HBM); WRITE_SIZE is exact for 16-B-per-lane stores.
 """
+import argparse
 import collections
 import csv
 import glob
+import json
 import os
+import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-def main(root):
+
+def main(root, json_path=None, n=None, count=None, source=None):
     agg = collections.defaultdict(list)
     dur = collections.defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True)):
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
             k = r["Kernel_Name"]
             if "nbk::" not in k:
@@ -26,6 +35,7 @@ def main(root):
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
             dur[short].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     kernels = sorted({k for k, _ in agg})
+    traffic = {}
     for k in kernels:
         print(f"== {k}   (mean duration under counters {sum(dur[k]) / len(dur[k]):.3f} ms, {len(dur[k])} samples)")
         vals = {c: sum(v) / len(v) for (kk, c), v in agg.items() if kk == k}
@@ -35,11 +45,32 @@ def main(root):
             rd, wr = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
             print(f"   -> HBM-side traffic per launch: read {rd / 1e6:.2f} MB (FETCH_SIZE x 2, gfx950 correction) + "
                   f"write {wr / 1e6:.2f} MB = {(rd + wr) / 1e6:.2f} MB")
+            base = re.sub(r"<.*$", "", k.replace("nbk::", ""))
+            # several instantiations of one kernel template in a run: keep the one with the most samples (the bench's own shape)
+            if base not in traffic or traffic[base]["samples"] < len(dur[k]):
+                traffic[base] = {"bytes_per_launch": int(rd + wr), "read": int(rd), "write": int(wr), "samples": len(dur[k]),
+                                 "kernel": k, "mean_ms_under_counters": sum(dur[k]) / len(dur[k])}
         if "SQ_WAVE_CYCLES" in vals and "SQ_ACTIVE_INST_ANY" in vals:
             wc = vals["SQ_WAVE_CYCLES"]
             print(f"   -> wave time: issuing {vals['SQ_ACTIVE_INST_ANY'] / wc:.1%}, issue-stalled "
                   f"{vals.get('SQ_WAIT_INST_ANY', 0) / wc:.1%}, parked (s_waitcnt/barrier) {vals.get('SQ_WAIT_ANY', 0) / wc:.1%}")
+    if json_path:
+        from nenbody_amd._lib import kernel_source_sha
+
+        out = {"_comment": "HBM-side bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 1024 x 2 [gfx950 correction for wide "
+                           "coalesced reads] + WRITE_SIZE x 1024). Written by tools/pmc_summary.py --json; bench.py reports the sum "
+                           "over a step's kernels as roofline.traffic when src_sha and the shape match.",
+               "n": n, "count": count, "src_sha": kernel_source_sha(), "source": source or root, "kernels": traffic}
+        json.dump(out, open(json_path, "w"), indent=1)
+        print(f"wrote {json_path}: {sorted(traffic)}", file=sys.stderr)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("root", nargs="?", default="gpurun_out/pmc")
+    ap.add_argument("--json")
+    ap.add_argument("--n", type=int, default=131072)
+    ap.add_argument("--count", type=int, default=131072)
+    ap.add_argument("--source")
+    a = ap.parse_args()
+    main(a.root, a.json, a.n, a.count, a.source)

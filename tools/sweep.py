@@ -116,13 +116,69 @@ def lanes_sweep(n_total=131072):
                               f"x{world}={dt * 1e3 * world:7.2f}", flush=True)
 
 
+def fast_groups_sweep(n_total=131072):
+    """FAST: one rank's share at world 1/2/4/8 over (bodies per lane, groups per workgroup, grid.y slices, tile)."""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    be = HipBackend()
+    dev = torch.device("cuda", 0)
+    pos, vel = nb.init_state(n_total, 1234)
+    cur = torch.zeros((n_total, 4)); cur[:, :3] = torch.from_numpy(pos); cur = cur.to(dev)
+    nxt = torch.zeros_like(cur)
+    # (bodies per lane, groups per workgroup, grid.y slices, tile, waves): waves != 0 = the barrier-free form (groups unused);
+    # all None = the library's own choice
+    shapes = {131072: [(4, 1, 32, 512, 0), (None,) * 5, (4, 0, 4, 256, 8), (4, 0, 8, 256, 8), (4, 0, 2, 256, 8), (4, 0, 1, 256, 8),
+                       (4, 0, 16, 256, 4), (4, 2, 16, 512, 0), (4, 4, 2, 512, 0), (4, 1, 32, 512, 0), (None,) * 5],
+              65536: [(4, 1, 32, 512, 0), (None,) * 5, (4, 0, 16, 256, 8)],
+              32768: [(4, 1, 64, 512, 0), (None,) * 5, (4, 0, 32, 256, 8)],
+              16384: [(2, 1, 64, 512, 0), (None,) * 5, (4, 0, 64, 256, 8), (2, 0, 32, 256, 8)]}
+    for count, lst in shapes.items():
+        for ib, groups, slices, tile, waves in lst:
+            env = {} if ib is None else {"NB_FAST_IB": ib, "NB_FAST_GROUPS": groups, "NB_FAST_SLICES": slices, "NB_TILE": tile,
+                                         "NB_FAST_WAVES": waves}
+            for k in ("NB_FAST_IB", "NB_FAST_GROUPS", "NB_FAST_SLICES", "NB_TILE", "NB_FAST_WAVES"):
+                os.environ.pop(k, None)
+            for k, v in env.items():
+                os.environ[k] = str(v)
+            nb.reload_env()
+            params = nb.default_params(mode=nb.NB_MODE_FAST)
+            v4 = torch.zeros((count, 4), device=dev)
+            sb = be.scratch_bytes(params, n_total, count)
+            scratch = torch.zeros((sb,), dtype=torch.uint8, device=dev) if sb else None
+            for _ in range(10):
+                be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
+            torch.cuda.synchronize()
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            world = n_total // count
+            print(f"fast count={count:7d} of {n_total} ib={ib} groups={groups} waves={waves} slices={slices} tile={tile} scratch={sb / 1e6:6.2f} MB "
+                  f"ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.3f}", flush=True)
+    for k in ("NB_FAST_IB", "NB_FAST_GROUPS", "NB_FAST_SLICES", "NB_TILE", "NB_FAST_WAVES"):
+        os.environ.pop(k, None)
+    nb.reload_env()
+    # standalone sets (the whole set in one launch), default shape against bodies per lane and the workgroup-tile form
+    for n in (1024, 4096, 8192, 16384, 32768, 1 << 20):
+        for env in ({}, {"NB_FAST_IB": 1}, {"NB_FAST_IB": 2}, {"NB_FAST_IB": 4}, {"NB_FAST_WAVES": 0}, {"NB_FAST_WAVES": 4}, {}):
+            if n == 1 << 20 and "NB_FAST_IB" in env:
+                continue
+            run(n, nb.NB_MODE_FAST, max(3, min(200, int(4e11 / (float(n) * n)))), env)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "strict"
-    known = {"strict", "strict2", "fast", "fast2", "shard", "lanes", "pc", "boids", "boidsshard", "configs", "strictone"}
+    known = {"strict", "strict2", "fast", "fast2", "fastgroups", "shard", "lanes", "pc", "boids", "boidsshard", "configs", "strictone"}
     if what not in known:
         raise SystemExit(f"unknown sweep {what!r}; one of {sorted(known)}")
     if what == "shard":
         return shard_sweep()
+    if what == "fastgroups":
+        return fast_groups_sweep()
     if what == "lanes":
         return lanes_sweep()
     if what == "strictone":
