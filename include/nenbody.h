@@ -286,6 +286,12 @@ void nb_shard_destroy(nb_shard *sh);
  * (ncclCommInitRank with the id from nb_comm_id). */
 int nb_shard_use_rccl(nb_shard *sh, const void *id);
 int nb_shard_use_gather(nb_shard *sh, nb_gather_fn fn, void *user);
+/* FAST only ("Overlap"): with `on` != 0 every step folds this rank's own slot of the snapshot while the
+ * exchange of the other slots is still in flight on a second stream, waits for it, then folds the rest (the two phases of
+ * nb_launch_step_phase).  The order of the additions changes, which FAST may and STRICT may not: a STRICT shard (and a world
+ * of one) ignores the request and stays kernel -> exchange in sequence.  A host-supplied exchange (nb_shard_use_gather)
+ * receives the second stream and must order its work on it. */
+int nb_shard_set_overlap(nb_shard *sh, int on);
 /* This rank's index range. */
 int nb_shard_range(const nb_shard *sh, uint32_t *first, uint32_t *count);
 /* Host -> device: ALL n positions and ALL n velocities (identical on every rank; the rank keeps its own velocities). */

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "nb_shard_destroy": (None, [c_void_p]),
     "nb_shard_use_rccl": (c_int, [c_void_p, c_void_p]),
     "nb_shard_use_gather": (c_int, [c_void_p, GATHER_FN, c_void_p]),
+    "nb_shard_set_overlap": (c_int, [c_void_p, c_int]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
     "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nb_shard_step": (c_int, [c_void_p, c_uint32]),

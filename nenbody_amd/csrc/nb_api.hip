@@ -42,7 +42,7 @@ struct Knob {
     bool on() const { return set && v != 0; }
 };
 struct DebugOverrides {
-    Knob tile, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
+    Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
         strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
@@ -68,6 +68,8 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_ib = read_knob("NB_FAST_IB");
     d->fast_groups = read_knob("NB_FAST_GROUPS");
     d->fast_waves = read_knob("NB_FAST_WAVES");
+    d->fast_sym = read_knob("NB_FAST_SYM");
+    d->fast_sym_slp = read_knob("NB_FAST_SYM_SLP");
     d->fast_slices = read_knob("NB_FAST_SLICES");
     d->fast_no_share = read_knob("NB_FAST_NO_SHARE");
     d->strict_force_ieee = read_knob("NB_STRICT_FORCE_IEEE");
@@ -105,6 +107,7 @@ bool valid_tile(uint32_t t) { return t == 256 || t == 512 || t == 1024; }
 struct Plan {
     uint32_t tile;
     uint32_t ib;      // FAST: bodies per thread
+    uint32_t sym;     // FAST: 0 = ordered pairs; else the pair-symmetric fold with this many waves per workgroup (whole-set launches)
     uint32_t waves;   // FAST: 0 = workgroup-tile form; else the barrier-free form with this many waves per workgroup (= groups)
     uint32_t groups;  // FAST: 256-lane groups per workgroup, each folding its own j chunk (combined in LDS)
     uint32_t slices;  // FAST: blockIdx.y slices of the j range (combined through memory)
@@ -212,6 +215,19 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         pl.ib = fast_bodies_per_lane(n_total, count);
         pl.waves = fast_wave_form();
         fast_split(n_total, count, pl.ib, pl.waves, &pl.tile, &pl.groups, &pl.slices, &pl.j_chunk);
+        // The pair-symmetric fold (step_fast_sym_kernel) is OPT-IN (NB_FAST_SYM = waves per workgroup: 2, 4 or 8): it needs
+        // both bodies of a pair on this GPU (whole-set launches, n a multiple of 64 * ib), and its rows of partial sums --
+        // one per superblock, n^2 / (256 * waves) * 16 B in all: 268 MB at n = 131 072 with 4 waves -- make it 9-14 %
+        // faster than the ordered fold at the price of 30-60 times the algorithmic HBM traffic.
+        pl.sym = 0;
+        if (count == n_total && dbg.fast_sym.on()) {
+            const uint32_t sib = dbg.fast_ib.set && dbg.fast_ib.v == 2 ? 2u : 4u;
+            if (n_total % (64u * sib) == 0) {
+                pl.sym = (dbg.fast_sym.v == 2 || dbg.fast_sym.v == 4 || dbg.fast_sym.v == 8) ? dbg.fast_sym.v : 4u;
+                if (sib == 2 && pl.sym == 2) pl.sym = 4;
+                pl.ib = sib;
+            }
+        }
     }
     // STRICT: magnitude range {0} U [2^a, 2^b] of coordinates for which d, n = dx*G, q = n/d and the
     // ladder's residuals are all normal binary32 with headroom, so that v_div_scale/v_div_fixup would be
@@ -283,6 +299,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
 size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
     if (pl.bc) return nbk::strict_bc_scratch_bytes(pl.n_total);
+    if (pl.sym) return (size_t)nbk::fast_sym_rows(pl.n_total, pl.ib, pl.sym) * count * sizeof(float4);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
 
@@ -447,6 +464,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, status, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
+                                              : pl.sym   ? (overrides().fast_sym_slp.on() ? nbk::launch_fast_sym_slp(a, pl.ib, pl.sym, stream) : nbk::launch_fast_sym(a, pl.ib, pl.sym, stream))
                                               : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
                                                          : nbk::launch_fast(a, pl.tile, pl.ib, pl.groups, pl.slices, stream);
     if (e != hipSuccess) {
@@ -1396,6 +1414,62 @@ NB_EXPORT size_t nb_scratch_bytes_phased(const nb_params *params, uint32_t n_tot
     return (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4);
 }
 
+namespace {
+// one phase of a FAST step on planned shapes (nb_launch_step_phase, nb_shard_step with the overlapped exchange)
+int launch_phase_planned(const nb_params &p, const PhasePlan &pp, uint32_t n_total, uint32_t first, uint32_t count, uint32_t j_lo,
+                         int phase, const void *pos_in, void *pos_out, void *vel, void *scratch, hipStream_t stream, std::string *err)
+{
+    const Plan &pl = pp.base;
+    nbk::StepArgs a{};
+    a.pos_in = (const float4 *)pos_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel = (float4 *)vel;
+    a.partial = (float4 *)scratch;
+    a.n_total = n_total;
+    a.first = first;
+    a.count = count;
+    a.dt = p.dt;
+    a.G = p.G;
+    a.bias = p.bias;
+    a.force_ieee = pl.force_ieee;
+    a.force_3d = pl.force_3d;
+    a.always_partial = 1;
+    hipError_t e = hipSuccess;
+    if (phase == NB_PHASE_RANGE) {  // records [j_lo, j_lo + len[0]) -> partial rows [0, slices[0])
+        a.j_count = pp.len[0];
+        a.j_base = j_lo;
+        a.hole_lo = 0xffffffffu;
+        a.hole_len = 0;
+        a.j_chunk = pp.chunk[0];
+        a.partial_row0 = 0;
+        if (pp.len[0])
+            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[0], stream)
+                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[0], pp.slices[0], stream);
+        else
+            e = hipMemsetAsync(scratch, 0, (size_t)pp.slices[0] * count * sizeof(float4), stream);
+    } else {  // the set without that range -> rows [slices[0], slices[0] + slices[1]), then every row in order + integrate
+        a.j_count = pp.len[1];
+        a.j_base = 0;
+        a.hole_lo = j_lo;
+        a.hole_len = pp.len[0];
+        a.j_chunk = pp.chunk[1];
+        a.partial_row0 = pp.slices[0];
+        if (pp.len[1])
+            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[1], stream)
+                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[1], pp.slices[1], stream);
+        else
+            e = hipMemsetAsync((char *)scratch + (size_t)pp.slices[0] * count * sizeof(float4), 0,
+                               (size_t)pp.slices[1] * count * sizeof(float4), stream);
+        if (e == hipSuccess) e = nbk::launch_integrate_partials(a, pp.slices[0] + pp.slices[1], stream);
+    }
+    if (e != hipSuccess) {
+        *err = std::string("nb: kernel launch failed (step phase): ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+}  // namespace
+
 NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, uint32_t j_lo,
                                    uint32_t j_hi, int phase, const void *pos_in, void *pos_out, void *vel, void *scratch,
                                    size_t scratch_bytes, void *stream)
@@ -1423,52 +1497,7 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
     }
     rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
-    const Plan &pl = pp.base;
-    nbk::StepArgs a{};
-    a.pos_in = (const float4 *)pos_in;
-    a.pos_out = (float4 *)pos_out;
-    a.vel = (float4 *)vel;
-    a.partial = (float4 *)scratch;
-    a.n_total = n_total;
-    a.first = first;
-    a.count = count;
-    a.dt = p.dt;
-    a.G = p.G;
-    a.bias = p.bias;
-    a.force_ieee = pl.force_ieee;
-    a.force_3d = pl.force_3d;
-    a.always_partial = 1;
-    hipError_t e = hipSuccess;
-    if (phase == NB_PHASE_RANGE) {  // records [j_lo, j_hi) -> partial rows [0, slices[0])
-        a.j_count = pp.len[0];
-        a.j_base = j_lo;
-        a.hole_lo = 0xffffffffu;
-        a.hole_len = 0;
-        a.j_chunk = pp.chunk[0];
-        a.partial_row0 = 0;
-        if (pp.len[0])
-            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[0], (hipStream_t)stream)
-                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[0], pp.slices[0], (hipStream_t)stream);
-        else e = hipMemsetAsync(scratch, 0, (size_t)pp.slices[0] * count * sizeof(float4), (hipStream_t)stream);
-    } else {  // the set without [j_lo, j_hi) -> rows [slices[0], slices[0] + slices[1]), then every row in order + integrate
-        a.j_count = pp.len[1];
-        a.j_base = 0;
-        a.hole_lo = j_lo;
-        a.hole_len = pp.len[0];
-        a.j_chunk = pp.chunk[1];
-        a.partial_row0 = pp.slices[0];
-        if (pp.len[1])
-            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[1], (hipStream_t)stream)
-                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[1], pp.slices[1], (hipStream_t)stream);
-        else e = hipMemsetAsync((char *)scratch + (size_t)pp.slices[0] * count * sizeof(float4), 0,
-                                (size_t)pp.slices[1] * count * sizeof(float4), (hipStream_t)stream);
-        if (e == hipSuccess) e = nbk::launch_integrate_partials(a, pp.slices[0] + pp.slices[1], (hipStream_t)stream);
-    }
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_launch_step_phase: kernel launch failed: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    return NB_OK;
+    return launch_phase_planned(p, pp, n_total, first, count, j_lo, phase, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
 }
 
 NB_EXPORT int nb_debug_reload_env(void)

@@ -31,7 +31,7 @@
 //   nb_nbody_strict.inc  STRICT arithmetic + step_strict_kernel<TJ,U,S>  (S = 1 here; S > 1 "j-parallel" in the SLP-off unit)
 //   nb_nbody_pc.inc      STRICT producer/consumer kernel                  (this unit)
 //   nb_nbody_bc.inc      STRICT block-chain kernel for small shards        (this unit)
-//   nb_nbody_fast.inc    FAST kernel + fixed-order combine                (this unit)
+//   nb_nbody_fast.inc    FAST kernels + fixed-order combine               (this unit; the pair-symmetric kernel: SLP-off unit)
 //   nb_aux.inc           model matrices, cameras, random walk, self-test  (this unit)
 //   nb_boids.inc         boids controller, one-lane and producer/consumer (SLP-off unit)
 //   nb_launch.inc        host-side launchers
@@ -53,6 +53,7 @@ static constexpr int kWaves = kBlock / 64;
 
 #ifdef NBK_NOSLP_TU
 #include "nb_boids.inc"
+#include "nb_nbody_fast.inc"  // for step_fast_sym_kernel only (its rotating sums are DPP operands: packed adds cannot take them)
 #else
 #include "nb_nbody_pc.inc"
 #include "nb_nbody_bc.inc"

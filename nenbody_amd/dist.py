@@ -277,7 +277,7 @@ class NativeShard:
     """
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, rank: int = 0, world: int = 1,
-                 comm_id: Optional[bytes] = None, gather=None):
+                 comm_id: Optional[bytes] = None, gather=None, overlap: bool = False):
         lib = _lib.load()
         pos = np.ascontiguousarray(positions, dtype=np.float32)
         vel = np.ascontiguousarray(velocities, dtype=np.float32)
@@ -310,6 +310,8 @@ class NativeShard:
 
                 self._gather_keepalive = _lib.GATHER_FN(trampoline)
                 self._check(lib.nb_shard_use_gather(self._sh, self._gather_keepalive, None))
+            if overlap:  # FAST only; a STRICT shard ignores it (nb_shard_set_overlap)
+                self._check(lib.nb_shard_set_overlap(self._sh, 1))
             self._check(lib.nb_shard_upload(self._sh, pos.ctypes.data, vel.ctypes.data))
         except Exception:
             self.close()

@@ -512,6 +512,61 @@ def test_fast_wave_form_every_launch_shape(nb, oracle, monkeypatch, ib, waves, s
         assert np.abs(p - p_ref).max() <= 2e-5, f"n={n}"
 
 
+@pytest.mark.parametrize("n,ib,sym", [(256, 4, 2), (1024, 4, 2), (2048, 4, 4), (4096, 4, 8), (2560, 4, 4), (6400, 4, 8), (1280, 2, 8), (640, 2, 4),
+                                      (32768, 4, 4)])
+def test_fast_pair_symmetric_fold(nb, oracle, monkeypatch, n, ib, sym):
+    """the pair-symmetric FAST fold (step_fast_sym_kernel): every unordered pair evaluated once and credited to both bodies --
+    the a-side in registers, the b-side in sums that rotate through the wave (DPP) and meet in LDS in a fixed order; diagonal
+    superblocks folded the ordered way.  Sizes with whole and partial superblocks (2560 = 10 blocks at 4 per superblock),
+    planar, 3-D and mixed tiles, coordinates too large for the shared reciprocal.  Opt-in (NB_FAST_SYM = waves per
+    workgroup); both builds of the kernel (with and without SLP packing).  Within FAST's tolerance of the oracle,
+    deterministic from run to run."""
+    monkeypatch.setenv("NB_FAST_SYM", str(sym))
+    monkeypatch.setenv("NB_FAST_IB", str(ib))
+    monkeypatch.setenv("NB_FAST_SYM_SLP", str(n // 256 % 2))
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    for flavour in ("3d", "planar", "mixed", "big"):
+        if n > 8192 and flavour != "planar":
+            continue
+        pos, vel = state3d(oracle, n, seed=n + len(flavour))
+        if flavour == "planar":
+            pos[:, 2] = 0
+            vel[:, 2] = 0
+        elif flavour == "mixed":
+            pos[:, 2] = 0
+            pos[n // 3:n // 3 + 100, 2] = np.linspace(-3, 3, 100, dtype=np.float32)
+        elif flavour == "big":
+            pos[7] = [3.0e9, -2.5e9, 1.0e9]
+            pos[n - 5] = [-4.0e9, 1.0, 7.0e9]
+        k = 1 if n > 8192 else 2
+        outs = []
+        for _ in range(2):
+            with nb.Scene(pos, vel, fast) as sc:
+                sc.step_n(k)
+                outs.append(sc.state())
+        assert_bits_equal(outs[0][0], outs[1][0], f"{flavour}: run-to-run determinism")
+        assert_bits_equal(outs[0][1], outs[1][1], f"{flavour}: run-to-run determinism (velocities)")
+        p, v = outs[0]
+        if n > 8192:
+            idx = np.unique(np.concatenate([[0, n - 1], np.linspace(0, n - 1, 60).astype(np.int64)]))
+            v_ref = np.concatenate([oracle.step_range(pos, vel[i:i + 1], int(i), 1)[1] for i in idx])
+            acc = np.abs(v_ref - vel[idx]).max()
+            assert np.abs(v[idx] - v_ref).max() <= 4e-5 * acc + float(np.spacing(np.abs(v_ref).max())), flavour
+            continue
+        p_ref, v_ref = oracle.run(pos, vel, k)
+        assert np.isfinite(p).all() and np.isfinite(v).all(), flavour
+        acc = np.abs(v_ref - vel).max()
+        tol = 4e-5 * acc + float(np.spacing(np.abs(v_ref).max()))
+        assert np.abs(v - v_ref).max() <= tol, f"{flavour}: {np.abs(v - v_ref).max():.3e} > {tol:.3e}"
+        assert np.abs(p - p_ref).max() <= 4e-5 * acc + float(np.spacing(np.abs(p_ref).max())), flavour
+    if n <= 8192:   # the same data through the ordered fold: the two must agree to FAST's tolerance
+        monkeypatch.setenv("NB_FAST_SYM", "0")
+        with nb.Scene(pos, vel, fast) as sc:
+            sc.step_n(k)
+            p0, v0 = sc.state()
+        assert np.abs(v0 - v).max() <= 2 * tol
+
+
 @pytest.mark.parametrize("waves", [0, 8])
 @pytest.mark.parametrize("n,first,count,j_lo,j_hi", [(6000, 0, 6000, 0, 750), (6000, 1500, 750, 1500, 2250), (6000, 5250, 750, 5250, 6000),
                                                      (5001, 1000, 333, 0, 0), (5001, 0, 5001, 0, 5001), (131072, 16384, 16384, 16384, 32768)])

@@ -9,7 +9,7 @@ OUT=${1:-gpurun_out/prof_r02}
 ROOT=$(pwd)
 mkdir -p "$OUT/stats" "$OUT/pmc"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/stats" -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats" -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
 echo "stats rc=$?"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_MISS_sum" \
            "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
     i=$((i + 1))
-    rocprofv3 --pmc $set --kernel-trace -d "$ROOT/$OUT/pmc/p$i" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc/p$i.log" 2>&1
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc/p$i" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc/p$i.log" 2>&1
     echo "pmc pass $i ($set) rc=$?"
 done
 find "$OUT" -name "*.csv" | head -40

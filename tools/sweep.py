@@ -172,13 +172,19 @@ def fast_groups_sweep(n_total=131072):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "strict"
-    known = {"strict", "strict2", "fast", "fast2", "fastgroups", "shard", "lanes", "pc", "boids", "boidsshard", "configs", "strictone"}
+    known = {"strict", "strict2", "fast", "fast2", "fastgroups", "fastsym", "shard", "lanes", "pc", "boids", "boidsshard", "configs", "strictone"}
     if what not in known:
         raise SystemExit(f"unknown sweep {what!r}; one of {sorted(known)}")
     if what == "shard":
         return shard_sweep()
     if what == "fastgroups":
         return fast_groups_sweep()
+    if what == "fastsym":
+        for n in (16384, 32768, 65536, 131072, 262144):
+            for env in ({"NB_FAST_SYM": 0}, {}, {"NB_FAST_SYM": 8}, {"NB_FAST_SYM": 4}, {"NB_FAST_SYM": 2}, {"NB_FAST_SYM": 8, "NB_FAST_IB": 2},
+                        {"NB_FAST_SYM": 8, "NB_FORCE_3D": 1}, {"NB_FAST_SYM": 0, "NB_FORCE_3D": 1}, {"NB_FAST_SYM": 0}, {}):
+                run(n, nb.NB_MODE_FAST, max(5, min(200, int(2e12 / (float(n) * n)))), env)
+        return
     if what == "lanes":
         return lanes_sweep()
     if what == "strictone":

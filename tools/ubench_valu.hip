@@ -18,11 +18,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-enum Kind { K_FMA = 0, K_PKFMA, K_PKMUL, K_PKADD, K_RCP, K_MUL, K_ADD, K_DIVSCALE, K_MIXFAST, K_MIXFAST_PK, K_NKINDS };
+enum Kind { K_FMA = 0, K_PKFMA, K_PKMUL, K_PKADD, K_RCP, K_MUL, K_ADD, K_DIVSCALE, K_MIXFAST, K_MIXFAST_PK, K_FMA_SGPR, K_PKMUL_SGPR, K_FMA_INLINE, K_ADD_LIT, K_NKINDS };
 static const char *kind_name[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "v_mul_f32",
-                                  "v_add_f32", "v_div_scale_f32", "mix:9fma+1rcp", "mix:pk(2 pairs)=9pk+2rcp"};
+                                  "v_add_f32", "v_div_scale_f32", "mix:9fma+1rcp", "mix:pk(2 pairs)=9pk+2rcp", "v_fma_f32 (SGPR src1)",
+                                  "v_pk_mul_f32 (SGPR pair)", "v_fma_f32 (inline 1.0)", "v_add_f32 (literal)"};
 // VALU instructions per loop iteration and "lane-ops" (scalar-equivalent ops) per instruction
-static const int insts_per_iter[] = {8, 8, 8, 8, 8, 8, 8, 8, 10, 11};
+static const int insts_per_iter[] = {8, 8, 8, 8, 8, 8, 8, 8, 10, 11, 8, 8, 8, 8};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters, float seed)
@@ -41,6 +42,25 @@ __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters, float seed)
       for (int rep = 0; rep < 8; ++rep) {
         if (KIND == K_FMA) {
 #define X(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(REP8(X) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+#undef X
+        } else if (KIND == K_FMA_SGPR) {  // the same stream with the multiplier in a scalar register
+            const float sb = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b)));
+#define X(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n\t"
+            asm volatile(REP8(X) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sb), "v"(c));
+#undef X
+        } else if (KIND == K_PKMUL_SGPR) {
+            const float sb1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b)));
+            f2 spb = {sb1, sb1};
+#define X(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(REP8(X) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(spb), "v"(pc));
+#undef X
+        } else if (KIND == K_FMA_INLINE) {  // an inline constant as the addend
+#define X(n) "v_fma_f32 %" #n ", %" #n ", %8, 1.0\n\t"
+            asm volatile(REP8(X) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(c));
+#undef X
+        } else if (KIND == K_ADD_LIT) {  // a 32-bit literal operand
+#define X(n) "v_add_f32 %" #n ", 0x3a83126f, %" #n "\n\t"
             asm volatile(REP8(X) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
 #undef X
         } else if (KIND == K_MUL) {
@@ -169,6 +189,10 @@ int main(int argc, char **argv)
     const int wps[] = {1, 2, 4, 8};
     for (int w : wps) {
         run<K_FMA>(w, iters);
+        run<K_FMA_SGPR>(w, iters);
+        run<K_FMA_INLINE>(w, iters);
+        run<K_ADD_LIT>(w, iters);
+        run<K_PKMUL_SGPR>(w, iters);
         run<K_MUL>(w, iters);
         run<K_ADD>(w, iters);
         run<K_PKFMA>(w, iters);
