@@ -13,7 +13,7 @@ once per step (RCCL).  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `value` = body-updates/s = N * steps / s of the whole job, STRICT arithmetic (the
 reference's own, bit for bit) unless --mode fast.  `roofline` prices the pair-fold kernel against the fp32 vector peak
 (the binding roofline: SURVEY.md section 8d) at the reference's 18 flop per interaction, and carries the rate
-this device's vector ALU was measured to sustain in the same process (`measured_fma_ceiling`).  `cpu_baseline` is the CPU
+this device's vector ALU was measured to issue in the same process (`measured_issue_ceiling`).  `cpu_baseline` is the CPU
 oracle (a C restatement of the reference's Rust; kind "port") timed on the host cores this process may really use.
 `targets` says which mode meets which line of BASELINE.json's north_star: no single mode meets both.
 
@@ -65,18 +65,18 @@ def committed_traffic(nb, kernels, n, count):
 
 def step_kernels(nb, mode, n, count):
     """the kernels one step launches, dominant one first (nb_api.hip:make_plan)"""
-    if mode == nb.NB_MODE_FAST:
-        return ["step_fast_kernel"]
+    if mode == nb.NB_MODE_FAST:  # 8-wave workgroups x grid.y slices; the slices' partial sums are combined by a second kernel
+        return ["step_fast_wave_kernel", "integrate_partials_kernel"]
     if count > 65536:
         return ["step_strict_kernel"]
     return ["step_strict_bc_kernel", "planes_kernel"] if n >= 4096 else ["step_strict_pc_kernel"]
 
 
-def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None):
+def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False):
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     params = nb.default_params(mode=mode)
-    sc = nb.ShardedScene(pos, vel, params)
+    sc = nb.ShardedScene(pos, vel, params, overlap=overlap)
     dev = sc.device
 
     def fence():
@@ -114,7 +114,8 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count else 0.0
+    # (the overlapped form launches its two phases through step_phase: no per-kernel events there, wall time only)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count and timed_step.i == len(ev) else 0.0
     return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps,
             "kernels": step_kernels(nb, mode, sc.n, sc.count), "mode": "fast" if mode == nb.NB_MODE_FAST else "strict"}
 
@@ -129,6 +130,9 @@ def main():
                     help="arithmetic of the headline number: strict = bit-identical to the reference (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs (other mode, 3-D data, boids)")
+    ap.add_argument("--overlap-leg", action="store_true",
+                    help="multi-GPU only: also time FAST with the exchange overlapped (ShardedScene(overlap=True)); off by default "
+                         "so that nothing untried on hardware can cost the scaling run its exit code")
     ap.add_argument("--aux-timeout", type=float, default=180.0,
                     help="seconds the informational legs (other mode, 3-D data, boids, CPU baseline) may take before the headline "
                          "is printed without them and the run exits 3")
@@ -232,20 +236,6 @@ def main():
     watchdog.daemon = True
     watchdog.start()
 
-    if world == 1:
-        leg["name"] = "measured_fma_ceiling"
-        try:
-            import ctypes
-
-            tf = ctypes.c_double()
-            nb._lib.check(nb.load().nb_selftest_fma_rate(0.05, ctypes.byref(tf)))
-            line["roofline"]["measured_fma_ceiling"] = {
-                "achieved": tf.value, "unit": "TFLOP/s", "frac_of_spec_peak": tf.value / PEAK_FP32_VECTOR_TFLOPS,
-                "what": "independent v_fma_f32 on every SIMD (8 waves each) for 50 ms in this process: what this device's "
-                        "vector ALU issues at the clock it holds under load"}
-        except Exception as e:  # pragma: no cover
-            line["roofline"]["measured_fma_ceiling"] = {"error": repr(e)}
-
     if not args.no_secondary:
         other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
         leg["name"] = "other_mode"
@@ -255,6 +245,16 @@ def main():
                                   "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
         except Exception as e:  # pragma: no cover
             line["other_mode"] = {"error": repr(e)}
+
+        if args.overlap_leg and world > 1:
+            leg["name"] = "fast_overlap"
+            try:
+                o = summarise(time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, overlap=True))
+                line["fast_overlap"] = {"what": "FAST, each step folds the rank's own slot while the all-gather of the others is in "
+                                                "flight (nb_launch_step_phase), then the rest",
+                                        "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"]}
+            except Exception as e:  # pragma: no cover
+                line["fast_overlap"] = {"error": repr(e)}
 
         # the same set with the planar shortcut switched off (NB_FORCE_3D=1): what 3-D data costs.  The reference's own
         # initial state is planar and stays planar (z = 0, vz = 0 is a fixed point of its arithmetic), which the headline rides.
@@ -299,6 +299,33 @@ def main():
                                         "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
         except Exception as e:  # pragma: no cover
             line["boids_controller"] = {"error": repr(e)}
+
+    if world == 1:
+        # Last of the GPU legs: these streams load the vector ALU harder than any kernel here, and the part answers a
+        # sustained load by lowering its clock for tens of milliseconds -- timed before the other legs they slow them down.
+        leg["name"] = "measured_issue_ceiling"
+        try:
+            import ctypes
+
+            rates = {}
+            for name, mix in (("fma", 0), ("mix", 1)):
+                r = ctypes.c_double()
+                nb._lib.check(nb.load().nb_selftest_valu_rate(mix, 0.05, ctypes.byref(r)))
+                rates[name] = r.value
+            ex = line["roofline"]["executed_per_interaction"]
+            slots = ex["full_rate_ops"] + 4.0 * ex["v_rcp_f32"]   # a quarter-rate v_rcp_f32 takes the slots of four
+            kernel_rate = slots * line["roofline"]["interactions_per_launch"] / (line["roofline"]["kernel_ms"] * 1e-3)
+            line["roofline"]["measured_issue_ceiling"] = {
+                "fma_stream_tflops": 2.0 * rates["fma"] / 1e12, "fma_stream_frac_of_spec_peak": 2.0 * rates["fma"] / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+                "mix_stream_lane_ops_per_s": rates["mix"], "fma_stream_lane_ops_per_s": rates["fma"],
+                "kernel_issue_slots_per_s": kernel_rate, "kernel_over_mix_stream": kernel_rate / rates["mix"],
+                "what": "register-only streams of independent vector instructions on every SIMD (8 waves each), 50 ms each, in this "
+                        "process after the timed legs: v_fma_f32 only (what the spec peak assumes; the part clocks down under it) and "
+                        "the folds' own mix of fma/add/mul/sub.  kernel_issue_slots_per_s = interactions/s x the issue slots the "
+                        "kernel executes per interaction (full-rate ops + 4 per v_rcp_f32): kernel_over_mix_stream says how close "
+                        "the kernel runs to what this device issues for that kind of instruction"}
+        except Exception as e:  # pragma: no cover
+            line["roofline"]["measured_issue_ceiling"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         leg["name"] = "cpu_baseline"

@@ -191,10 +191,12 @@ int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, u
 int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
 int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
 
-/* Diagnostic: the fp32 rate the vector ALU of THIS device sustains at the clock it holds under load -- a stream of
- * independent v_fma_f32 on every SIMD (8 waves each) for about `seconds` (<= 2) -- in TFLOP/s (2 flop per lane-op).
- * bench.py prints it beside the spec peak its roofline fraction is quoted against. */
-int nb_selftest_fma_rate(double seconds, double *tflops);
+/* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
+ * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
+ * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in
+ * the proportion of the pair folds (same issue slots, less power: the part clocks it higher).  bench.py prints both beside
+ * the spec peak its roofline fraction is quoted against. */
+int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
 
 /* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
  * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,

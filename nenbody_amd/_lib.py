@@ -94,7 +94,7 @@ PROTOTYPES = {
     "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
     "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
-    "nb_selftest_fma_rate": (c_int, [ctypes.c_double, POINTER(ctypes.c_double)]),
+    "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double)]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),

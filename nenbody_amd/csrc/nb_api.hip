@@ -1266,10 +1266,10 @@ NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
     return NB_OK;
 }
 
-NB_EXPORT int nb_selftest_fma_rate(double seconds, double *tflops)
+NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s)
 {
-    if (!tflops || !(seconds > 0.0) || seconds > 2.0) {
-        g_tls_error = "nb_selftest_fma_rate: need tflops != NULL and 0 < seconds <= 2";
+    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix != 0 && mix != 1)) {
+        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0 or 1 and 0 < seconds <= 2";
         return NB_ERR_INVALID;
     }
     int rc = check_device(&g_tls_error);
@@ -1285,7 +1285,7 @@ NB_EXPORT int nb_selftest_fma_rate(double seconds, double *tflops)
     const uint32_t blocks = (uint32_t)cus * 8u;  // 256 lanes = one wave per SIMD each: 8 waves per SIMD
     auto timed = [&](uint32_t trips, float *ms) {
         hipError_t x = hipEventRecord(e0, nullptr);
-        if (x == hipSuccess) x = nbk::launch_fma_stream(blocks, trips, sink, nullptr);
+        if (x == hipSuccess) x = nbk::launch_valu_stream(mix, blocks, trips, sink, nullptr);
         if (x == hipSuccess) x = hipEventRecord(e1, nullptr);
         if (x == hipSuccess) x = hipEventSynchronize(e1);
         if (x == hipSuccess) x = hipEventElapsedTime(ms, e0, e1);
@@ -1303,11 +1303,10 @@ NB_EXPORT int nb_selftest_fma_rate(double seconds, double *tflops)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess || !(ms > 0.f)) {
-        g_tls_error = std::string("nb_selftest_fma_rate: ") + hipGetErrorString(e);
+        g_tls_error = std::string("nb_selftest_valu_rate: ") + hipGetErrorString(e);
         return NB_ERR_HIP;
     }
-    const double flop = 2.0 * 64.0 * (double)trips * 256.0 * (double)blocks;
-    *tflops = flop / ((double)ms * 1e-3) / 1e12;
+    *lane_ops_per_s = 64.0 * (double)trips * 256.0 * (double)blocks / ((double)ms * 1e-3);
     return NB_OK;
 }
 

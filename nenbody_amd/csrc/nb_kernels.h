@@ -68,8 +68,8 @@ hipError_t launch_ladder_exhaustive(uint32_t first_md, uint32_t count_md, bool c
                                     hipStream_t s);
 // v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for all 2^23 significands m and k in [k_lo, k_hi]
 hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations, hipStream_t s);
-// `blocks` workgroups of 256 lanes each issue trips * 64 independent v_fma_f32 per lane
-hipError_t launch_fma_stream(uint32_t blocks, uint32_t trips, float *sink, hipStream_t s);
+// `blocks` workgroups of 256 lanes each issue trips * 64 register-only vector instructions per lane (mix 0: v_fma_f32; 1: the folds' mix)
+hipError_t launch_valu_stream(int mix, uint32_t blocks, uint32_t trips, float *sink, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

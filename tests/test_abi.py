@@ -267,16 +267,17 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
 
     lib = _lib.load()
     tf = ctypes.c_double()
-    assert lib.nb_selftest_fma_rate(0.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_fma_rate(0.05, None) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_fma_rate(5.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(0, 0.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(0, 0.05, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(1, 5.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(2, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
     bad = ctypes.c_uint64()
     assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_rcp_scaling(5, 4, ctypes.byref(bad)) == _lib.NB_ERR_INVALID
     if lib.nb_device_count() > 0:
         pytest.skip("a HIP device is present")
     assert lib.nb_launch_status(None) == _lib.NB_ERR_NO_DEVICE
-    assert lib.nb_selftest_fma_rate(0.05, ctypes.byref(tf)) == _lib.NB_ERR_NO_DEVICE
+    assert lib.nb_selftest_valu_rate(0, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_NO_DEVICE
     # the boids drop-in pads the shorter snapshot on the host before it needs the device
     pos, vel = nb.init_state(12)
     with pytest.raises(nb.NbError) as ei:
