@@ -1,23 +1,35 @@
 #!/bin/bash
 # profile_bench.sh OUTDIR -- the rocprofv3 evidence of one round, run on the GPU box from the repo root:
-#   OUTDIR/stats   rocprofv3 --kernel-trace --stats of the bench command (kernel_stats: average duration per kernel)
-#   OUTDIR/pmc/pN  one --pmc pass per counter set (never combined with a trace domain other than --kernel-trace),
-#                  over a short bench run; tools/pmc_summary.py reduces them (and writes profiles/hbm_traffic.json)
+#   OUTDIR/stats_{strict,fast}  rocprofv3 --kernel-trace --stats of `bench.py --mode M --no-secondary`: ONE arithmetic per run, so
+#                               a kernel's average duration is that of the bench's own timed launches (the 3-D leg of the full
+#                               bench runs the same kernel template on slower data and would skew it)
+#   OUTDIR/stats_all            the same of the full default bench command (boids, 3-D legs, the issue-ceiling streams)
+#   OUTDIR/pmc/M_pN             one --pmc pass per counter set and arithmetic (never combined with a trace domain other than
+#                               --kernel-trace), over a short bench run; tools/pmc_summary.py reduces them (and writes
+#                               profiles/hbm_traffic.json)
 # The program after `--` is python3 itself (no env / bash -c hop: the profiler has initialised the GPU by then).
 set -u
 OUT=${1:-gpurun_out/prof_r02}
 ROOT=$(pwd)
-mkdir -p "$OUT/stats" "$OUT/pmc"
+mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats" -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
-echo "stats rc=$?"
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" \
-           "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" \
-           "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_MISS_sum" \
-           "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
-    i=$((i + 1))
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc/p$i" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc/p$i.log" 2>&1
-    echo "pmc pass $i ($set) rc=$?"
+for mode in strict fast; do
+    mkdir -p "$OUT/stats_$mode"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$mode" -- python3 "$ROOT/bench.py" --mode $mode --no-secondary --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${mode}_under_rocprof.log" 2>&1
+    echo "stats $mode rc=$?"
 done
-find "$OUT" -name "*.csv" | head -40
+mkdir -p "$OUT/stats_all"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_all" -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_all_under_rocprof.log" 2>&1
+echo "stats all rc=$?"
+for mode in strict fast; do
+    i=0
+    for set in "FETCH_SIZE" "WRITE_SIZE" \
+               "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" \
+               "VALUBusy VALUUtilization" "TCC_HIT_sum TCC_MISS_sum" \
+               "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
+        i=$((i + 1))
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc/${mode}_p$i" -- python3 "$ROOT/bench.py" --mode $mode --no-secondary --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc/${mode}_p$i.log" 2>&1
+        echo "pmc $mode pass $i ($set) rc=$?"
+    done
+done
+find "$OUT" -name "*.csv" | wc -l
