@@ -131,6 +131,9 @@ public:
     uint32_t count() const { return count_; }
     void step(uint32_t k = 1) { check_sh(nb_shard_step(sh_, k)); }
     void step_boids(uint32_t k = 1, const nb_boids_params *params = nullptr) { check_sh(nb_shard_step_boids(sh_, k, params)); }
+    // FAST only (a STRICT shard ignores it): fold the rank's own slot while the exchange of the others is in flight
+    void set_overlap(bool on) { check_sh(nb_shard_set_overlap(sh_, on ? 1 : 0)); }
+    // waits; throws Error(NB_ERR_STATE) if a kernel of this shard reported a failure (a block-chain wave gave up waiting)
     void sync() { check_sh(nb_shard_sync(sh_)); }
     // all n positions (the replica); this rank's velocities and model matrices
     void download(std::vector<Vec3> &positions, std::vector<Vec3> &velocities_local, std::vector<Mat4> &instances_local)

@@ -285,3 +285,20 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     assert ei.value.status == _lib.NB_ERR_NO_DEVICE
     with pytest.raises(nb.NbError):
         nb.update_instance_boids(np.zeros((12, 4, 4), np.float32), pos[:5].copy(), pos[:5].copy(), vel, vel.copy())
+
+
+def test_committed_hbm_traffic_is_of_the_current_kernel_sources(nb):
+    """bench.py reports roofline.traffic from profiles/hbm_traffic.json only when the file's stamp is the sha of the kernel
+    sources that are running (tools/pmc_summary.py --json writes both).  A kernel edit without a new rocprofv3 --pmc run
+    leaves the file stale -- bench.py then reports traffic = null with the reason; this test makes that visible here."""
+    import json
+
+    from nenbody_amd import _lib
+
+    t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert set(t) >= {"n", "count", "src_sha", "kernels", "source"} and t["n"] == 131072 and t["count"] == 131072
+    for k in ("step_strict_kernel", "step_fast_wave_kernel", "integrate_partials_kernel"):
+        assert t["kernels"][k]["bytes_per_launch"] == t["kernels"][k]["read"] + t["kernels"][k]["write"] > 0
+    if t["src_sha"] != _lib.kernel_source_sha():
+        pytest.skip("profiles/hbm_traffic.json is stale (kernel sources changed since the PMC passes): re-run tools/profile_bench.sh "
+                    "and tools/pmc_summary.py --json")
