@@ -182,14 +182,16 @@ def load() -> ctypes.CDLL:
 
 
 def kernel_source_sha() -> str:
-    """sha256 (first 16 hex digits) over the kernel and host sources of the library, in name order: stamps measurements
+    """sha256 (first 16 hex digits) over the KERNEL sources of the library (nb_kernels.hip, nb_kernels.h and the nb_*.inc it
+    includes, launchers included; not the host-side ABI files nb_api.hip / nb_shard.inc), in name order: stamps measurements
     (profiles/hbm_traffic.json) with the code they were taken from, so a stale profile is recognised."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
-    for path in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.h"))):
+    files = [os.path.join(src, "nb_kernels.hip"), os.path.join(src, "nb_kernels.h")] + glob.glob(os.path.join(src, "nb_*.inc"))
+    for path in sorted(f for f in files if os.path.basename(f) != "nb_shard.inc"):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]

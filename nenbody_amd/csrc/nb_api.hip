@@ -701,7 +701,7 @@ constexpr uint32_t kRoundtripMax = 16384;
 
 static int ensure_xfer(nb_ctx *c)
 {
-    const size_t bytes = (size_t)c->n * 22 * sizeof(float);
+    const size_t bytes = ((size_t)c->n * 22 + 16) * sizeof(float);  // + a tail word: the status word rides along (update_roundtrip)
     if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, bytes));
     if (!c->hxfer) NB_HIP(c, hipHostMalloc((void **)&c->hxfer, bytes, hipHostMallocDefault));
     return NB_OK;
@@ -1023,12 +1023,23 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
     rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
     if (rc != NB_OK) return rc;
     NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)c->xfer, c->xfer + 16 * n, c->xfer + 19 * n, c->stream));
-    NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, n * 22 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    // the sticky status word of this context's block-chain launches comes home in the same copy: no second wait per frame
+    const bool with_status = c->status.dirty && c->status.w;
+    if (with_status) NB_HIP(c, hipMemcpyAsync(c->xfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
+    if (with_status) {
+        uint32_t v;
+        std::memcpy(&v, c->hxfer + 22 * n, sizeof(v));
+        if (v == 0u)
+            c->status.dirty = false;
+        else
+            return check_status(&c->status, &c->err);  // reads it again, clears it, reports NB_ERR_STATE
+    }
     std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));
     std::memcpy(pos_out, c->hxfer + 16 * n, count * xyz);
     std::memcpy(vel_out, c->hxfer + 19 * n, count * xyz);
-    return check_status(&c->status, &c->err);
+    return NB_OK;
 }
 
 int update_common(const char *who, bool boids, float *inst, size_t n_inst, float *pos, size_t n_pos, float *opos, size_t n_opos,
