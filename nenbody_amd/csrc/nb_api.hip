@@ -43,7 +43,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo;
+        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo, roctx;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -85,6 +85,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_force = read_knob("NB_BOIDS_FORCE");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
     d->shard_rccl_solo = read_knob("NB_SHARD_RCCL_SOLO");
+    d->roctx = read_knob("NB_ROCTX");
     d->generation = generation;
     return d;
 }
@@ -338,6 +339,45 @@ int cached_plan(const nb_params &p, uint32_t n_total, uint32_t count, const Plan
     *out = &e.pl;
     return NB_OK;
 }
+
+// ---- roctx ranges (tracing) -----------------------------------------------------------------
+// NB_ROCTX=1: the step loops of the context and shard APIs are bracketed with roctx ranges ("nb_step", "nb_shard_step",
+// "nb_shard_exchange", ...), which rocprofv3 --marker-trace puts on the timeline.  The library is loaded with dlopen at first
+// use (librocprofiler-sdk-roctx.so, else libroctx64.so); without NB_ROCTX nothing is loaded and a range costs one branch.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx *roctx_api()
+{
+    if (!overrides().roctx.on()) return nullptr;
+    static const Roctx *api = [] {
+        Roctx *r = new Roctx();
+        void *h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            r->push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            r->pop = (int (*)())dlsym(h, "roctxRangePop");
+        }
+        return (const Roctx *)r;
+    }();
+    return (api->push && api->pop) ? api : nullptr;
+}
+struct RoctxRange {
+    const Roctx *api;
+    explicit RoctxRange(const char *name) : api(roctx_api())
+    {
+        if (api) (void)api->push(name);
+    }
+    ~RoctxRange()
+    {
+        if (api) (void)api->pop();
+    }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
 
 // ---- sticky device status ------------------------------------------------------------------------------------
 // One word per device, owned by the library, zero at allocation.  The block-chain kernel ORs 1 into it when a wave gave
@@ -806,6 +846,7 @@ NB_EXPORT int nb_step(nb_ctx *ctx, uint32_t k)
         ctx->err = "nb_step: no state uploaded (call nb_upload first)";
         return NB_ERR_STATE;
     }
+    RoctxRange range("nb_step");
     for (uint32_t s = 0; s < k; ++s) {
         int rc = launch_step_planned(ctx->p, ctx->plan, ctx->n, 0, ctx->n, ctx->pos[ctx->cur], ctx->pos[ctx->cur ^ 1],
                                      ctx->vel, ctx->scratch, ctx->stream, &ctx->err, &ctx->status);
@@ -849,6 +890,7 @@ NB_EXPORT int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *para
     int rc = make_boids_args(p, ctx->n, 0, ctx->n, &a, &tile, &ctx->err);
     if (rc != NB_OK) return rc;
     if (!ctx->vel_alt) NB_HIP(ctx, hipMalloc((void **)&ctx->vel_alt, (size_t)ctx->n * sizeof(float4)));
+    RoctxRange range("nb_step_boids");
     for (uint32_t s = 0; s < k; ++s) {
         a.pos_in = ctx->pos[ctx->cur];
         a.pos_out = ctx->pos[ctx->cur ^ 1];

@@ -1058,3 +1058,18 @@ def test_block_chain_ieee_fallback_in_the_same_kernel(nb, oracle, monkeypatch):
     p_ref, v_ref = oracle.run(pos, vel, 2)
     assert_bits_equal(p, p_ref)
     assert_bits_equal(v, v_ref)
+
+
+def test_roctx_ranges_do_not_change_results(nb, oracle, monkeypatch):
+    """NB_ROCTX=1 brackets the step loops with roctx ranges (dlopen of the roctx library at first use): same bits."""
+    monkeypatch.setenv("NB_ROCTX", "1")
+    pos, vel = state3d(oracle, 700, seed=3)
+    with nb.Scene(pos, vel) as sc:
+        sc.step_n(3)
+        p, v = sc.state()
+    p_ref, v_ref = oracle.run(pos, vel, 3)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+    with nb.NativeShard(pos, vel) as sh:
+        sh.step(2)
+        assert_bits_equal(sh.positions(), oracle.run(pos, vel, 2)[0])
