@@ -42,15 +42,15 @@ pos, vel = nb.init_state(n, 1234)
 class SoloScene(nb.ShardedScene):
     """rank 0 of `world`, with the exchange issued on the one-rank group: in place on this rank's own slot"""
 
-    def _all_gather_slots(self, buf):
+    def _all_gather_slots(self, buf, async_op=False):
         mine = buf[: self.slot]
-        self.dist.all_gather_into_tensor(mine, mine)
+        return self.dist.all_gather_into_tensor(mine, mine, async_op=async_op)
 
 
-def python_path(mode, exchange=True):
-    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0)
+def python_path(mode, exchange=True, overlap=False):
+    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0, overlap=overlap)
     if not exchange:
-        sc._all_gather_slots = lambda buf: None
+        sc._all_gather_slots = lambda buf, async_op=False: None
     for _ in range(10):
         sc.step()
     sc.sync()
@@ -71,6 +71,9 @@ def python_path(mode, exchange=True):
         sc.step()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
+    if overlap:  # two phases through step_phase: wall time only
+        sc.sync()
+        return wall, float("nan")
     # pass 2: device time of the step's kernels
     timed.i = 0
     sc.backend.step = timed
@@ -83,10 +86,10 @@ def python_path(mode, exchange=True):
     return wall, dev
 
 
-def native_path(mode):
+def native_path(mode, overlap=False):
     os.environ["NB_SHARD_RCCL_SOLO"] = "1"
     nb.reload_env()
-    sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id())
+    sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id(), overlap=overlap)
     sh.step(10)
     sh.sync()
     t0 = time.perf_counter()
@@ -108,4 +111,11 @@ for name, mode in (("STRICT", nb.NB_MODE_STRICT), ("FAST", nb.NB_MODE_FAST)):
     print(f"{name:6s} ShardedScene, no exchange : wall/step {w_noex * 1e6:8.1f} us  overhead {(w_noex - dev) * 1e6:7.1f} us", flush=True)
     print(f"{name:6s} ShardedScene + all-gather : wall/step {w_py * 1e6:8.1f} us  overhead {(w_py - dev) * 1e6:7.1f} us", flush=True)
     print(f"{name:6s} NativeShard  + all-gather : wall/step {w_c * 1e6:8.1f} us  overhead {(w_c - dev) * 1e6:7.1f} us", flush=True)
+    if mode == nb.NB_MODE_FAST:
+        # the overlapped form: own-slot phase, wait for the (asynchronous) exchange, rest phase -- on one GPU there is nothing
+        # to hide behind the first phase, so this shows what the phasing itself costs
+        w_ov, _ = python_path(mode, overlap=True)
+        w_cov = native_path(mode, overlap=True)
+        print(f"{name:6s} ShardedScene, overlapped  : wall/step {w_ov * 1e6:8.1f} us  ({(w_ov - w_py) * 1e6:+.1f} us against the plain step)", flush=True)
+        print(f"{name:6s} NativeShard,  overlapped  : wall/step {w_cov * 1e6:8.1f} us  ({(w_cov - w_c) * 1e6:+.1f} us against the plain step)", flush=True)
 dist.destroy_process_group()
