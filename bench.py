@@ -296,7 +296,11 @@ def main():
                 dist.all_reduce(bt, op=dist.ReduceOp.MAX)
             line["boids_controller"] = {"metric": "body-updates/s, update_instance_boids (bit-exact)",
                                         "value": n * bsteps / float(bt.item()),
-                                        "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps}
+                                        "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps,
+                                        "pair_evaluations_per_s": float(n) * n * bsteps / float(bt.item()),
+                                        "executed_per_pair": {"full_rate_ops": 16,
+                                                              "note": "planar tiles whose velocities cannot fail the rule-3 test "
+                                                                      "(the reference's constants: every tile); 24 when it is tested"}}
         except Exception as e:  # pragma: no cover
             line["boids_controller"] = {"error": repr(e)}
 

@@ -559,11 +559,47 @@ float sqrt_threshold(float r)
     return x;
 }
 
-// boids launch shape: the producer/consumer form below 80 K bodies per rank, one lane per body above (NB_BOIDS_PC overrides).
-// Measured at N = 131 072 (tools/sweep.py boidsshard): 65 536 bodies 6.68 ms against 7.82; 131 072: 13.4 against 8.5.
+// Largest binary32 V >= 0 such that rule 3 (main.rs:497-498) holds for EVERY pair of velocities whose components all lie in
+// [-V, V], or -1 if there is none.  |v_i - v_n| <= 2V per component (2V is representable, rounding is monotonic), so the
+// squared distance as the reference rounds it, ((ex*ex) + (ey*ey)) + (ez*ez), is at most the same expression at
+// ex = ey = ez = 2V; the bound is monotonic in V, so bisection over the bit patterns finds the largest V that keeps it <= t3.
+float rule3_always_bound(float t3)
+{
+    if (!(t3 >= 0.0f)) return -1.0f;
+    auto holds = [&](uint32_t b) {
+        float v;
+        std::memcpy(&v, &b, 4);
+        const volatile float w = v + v;
+        const volatile float q = w * w;
+        const volatile float two = q + q;
+        const volatile float bound = two + q;
+        return bound <= t3;  // false when anything overflowed to +inf
+    };
+    uint32_t lo = 0u, hi = 0x7f7fffffu;
+    if (!holds(lo)) return -1.0f;
+    if (!holds(hi)) {
+        while (hi - lo > 1u) {  // invariant: holds(lo) && !holds(hi)
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (holds(mid))
+                lo = mid;
+            else
+                hi = mid;
+        }
+    } else {
+        lo = hi;
+    }
+    float x;
+    std::memcpy(&x, &lo, 4);
+    return x;
+}
+
+// boids launch shape: the producer/consumer form below 56 K bodies per rank, one lane per body above (NB_BOIDS_PC overrides).
+// Measured at N = 131 072 (tools/sweep.py boidsshard, profiles/r02/boids_forms.log): one lane per body takes 4.65 ms for any
+// shard up to 65 536 bodies (a lone wave per SIMD) and 4.9-5.3 for the whole set; producer/consumer 0.083 ms per 1 024 bodies
+// (16 384: 1.43, 32 768: 2.75, 65 536: 5.41).
 uint32_t boids_use_pc(uint32_t count)
 {
-    return overrides().boids_pc.or_else(count < 81920u ? 1u : 0u);
+    return overrides().boids_pc.or_else(count < 57344u ? 1u : 0u);
 }
 
 int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,
@@ -593,7 +629,12 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
         *err = "nb: boids: neighbour counts are kept in binary32 and need n_total < 2^24";
         return NB_ERR_UNSUPPORTED;
     }
-    a.force_flags = overrides().boids_force.or_else(0u) & 3u;
+    a.force_flags = overrides().boids_force.or_else(0u) & 7u;
+    const float v_lim = rule3_always_bound(a.t3);
+    if (v_lim < 0.0f)
+        a.force_flags |= 4u;  // no such bound (rule_3_distance <= 0 or NaN): always test
+    else
+        std::memcpy(&a.vlim_bits, &v_lim, 4);
     *out = a;
     *tile = t;
     return NB_OK;

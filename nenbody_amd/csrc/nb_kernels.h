@@ -38,7 +38,8 @@ struct BoidsArgs {
     float r1;              // rule_1_distance, compared with the squared distance (main.rs:451, 474-475)
     float t2, t3;          // squared-distance thresholds equivalent to sqrt(d2) < rule_2_distance / rule_3_distance
     float s1, s2, s3;      // rule scales, main.rs:454-456
-    uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form (tests)
+    uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form, 4 = always test rule 3 (tests)
+    uint32_t vlim_bits;    // bit pattern of v_lim: velocity components of at most this magnitude cannot fail the rule-3 test (nb_boids.inc, ALL3)
 };
 hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t pc, hipStream_t s);  // pc != 0: producer/consumer form (64 bodies x 16 waves)
 

@@ -26,10 +26,12 @@ def cloud(oracle, n, seed, scale=0.3):
     return (pos * np.float32(scale)).astype(np.float32), vel
 
 
-@pytest.fixture(params=[(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 1), (3, 1)],
-                ids=["auto", "select", "masked3d", "select3d", "pc-auto", "pc-select", "pc-masked3d", "pc-select3d"])
+@pytest.fixture(params=[(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (6, 0), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (6, 1)],
+                ids=["auto", "select", "masked3d", "select3d", "rule3-tested", "rule3-tested-3d", "pc-auto", "pc-select", "pc-masked3d",
+                     "pc-select3d", "pc-rule3-tested", "pc-rule3-tested-3d"])
 def force(request, monkeypatch):
-    """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form;
+    """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form,
+    4 = always evaluate the rule-3 test (never the form that knows it holds for the whole tile);
     NB_BOIDS_PC: one lane per body (0) or the producer/consumer form (1).  Every form must give the same bits."""
     monkeypatch.setenv("NB_BOIDS_FORCE", str(request.param[0]))
     monkeypatch.setenv("NB_BOIDS_PC", str(request.param[1]))
@@ -150,6 +152,62 @@ def test_boids_velocity_radius_and_custom_constants(nb, oracle):
         p_ref, v_ref = oracle.boids_run(pos, vel, 2, obp)
         assert_bits_equal(v, v_ref, f"r3={r3} r2={r2} r1={r1}")
         assert_bits_equal(p, p_ref, f"r3={r3} r2={r2} r1={r1}")
+
+
+def _rule3_bound(t3):
+    """the host's v_lim restated: largest binary32 V with ((2V)^2 + (2V)^2) + (2V)^2 <= t3, every operation in binary32"""
+    def holds(b):
+        v = np.array([b], np.uint32).view(np.float32)[0]
+        with np.errstate(over="ignore"):
+            w = np.float32(v + v)
+            q = np.float32(w * w)
+            return np.float32(np.float32(q + q) + q) <= t3
+    lo, hi = 0, 0x7f7fffff
+    assert holds(lo) and not holds(hi)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        lo, hi = (mid, hi) if holds(mid) else (lo, mid)
+    return np.array([lo], np.uint32).view(np.float32)[0]
+
+
+@pytest.mark.parametrize("pc", ["0", "1"], ids=["lane-per-body", "producer-consumer"])
+@pytest.mark.parametrize("planar", [True, False])
+def test_boids_rule3_known_to_hold_per_tile(nb, oracle, monkeypatch, planar, pc):
+    """Tiles whose velocity components all stay within the host's bound skip the rule-3 test (it cannot fail there);
+    tiles with one component a single ulp above the bound evaluate it.  Velocities sit AT the bound, one ulp above it,
+    and far above it (where the test does fail), so a wrong bound or a wrong flag shows as different bits."""
+    monkeypatch.setenv("NB_BOIDS_PC", pc)
+    n = 5000
+    pos, vel = (oracle.init_state(n, 77) if planar else cloud(oracle, n, 77))
+    pos *= np.float32(0.2)
+    r3 = np.float32(1.0)
+    t3 = np.float32(1.0)
+    while np.sqrt(np.nextafter(t3, np.float32(2))) < r3:      # largest x with sqrt(x) < r3 is below 1: walk down
+        t3 = np.nextafter(t3, np.float32(2))
+    while not np.sqrt(t3) < r3:
+        t3 = np.nextafter(t3, np.float32(0))
+    vlim = _rule3_bound(t3)
+    assert 0.28 < vlim < 0.29                                 # 1 / (2 sqrt 3)
+    rng = np.random.default_rng(3)
+    vel[:, :2] = rng.uniform(-vlim, vlim, (n, 2)).astype(np.float32)
+    vel[:, 2] = 0 if planar else rng.uniform(-vlim, vlim, n).astype(np.float32)
+    vel[10] = [vlim, -vlim, 0 if planar else vlim]           # at the bound: still inside
+    vel[11] = [-vlim, vlim, 0 if planar else -vlim]          # the farthest pair the bound admits
+    vel[1100, 0] = np.nextafter(vlim, np.float32(1))          # one ulp outside: its tile tests
+    vel[2300] = [0.9, -0.8, 0]                                # fails the test against most bodies
+    vel[4000:4100, 1] = np.float32(-0.6)                      # a run of bodies outside: their own workgroup tests everywhere
+    bp, obp = nb.default_boids_params(), oracle.boids_params()
+    bp.rule_3_distance = obp.rule_3_distance = float(r3)
+    outs = {}
+    for knob in ("0", "4"):
+        monkeypatch.setenv("NB_BOIDS_FORCE", knob)
+        with nb.Scene(pos, vel) as sc:
+            sc.step_boids_n(2, bp)
+            outs[knob] = sc.state()
+    p_ref, v_ref = oracle.boids_run(pos, vel, 2, obp)
+    for knob, (p, v) in outs.items():
+        assert_bits_equal(v, v_ref, f"velocities, NB_BOIDS_FORCE={knob}")
+        assert_bits_equal(p, p_ref, f"positions, NB_BOIDS_FORCE={knob}")
 
 
 def test_boids_nonfinite_positions_like_the_reference(nb, oracle):
