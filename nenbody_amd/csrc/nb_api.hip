@@ -283,14 +283,18 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     // body).  Default there: the block-chain form (nb_nbody_bc.inc).  Against all 131 072 bodies: 16 384 bodies 0.85 ms
     // (producer/consumer, 14 producers + 2 consumers per 64 bodies: 1.15; j-parallel S = 8: 2.1), 32 768: 1.67 (2.28),
     // 65 536: 3.30 (one lane per body 3.52); the whole set: 6.57 against 6.19 for one lane per body, which therefore keeps
-    // everything above (profiles/r01_final/pc_sweep.log).  It needs scratch memory (nb_scratch_bytes).  Sets below 4 096
-    // bodies stay with producer/consumer: there the block chain's extra launch costs more than the form gains.
+    // everything above (profiles/r01_final/pc_sweep.log).  It needs scratch memory (nb_scratch_bytes).
+    // Small SETS (tools/small_forms.py, profiles/r02/small_forms.log; microseconds per step, j-parallel / producer-consumer /
+    // block chain): N = 100: 3.7 / 4.3 / 6.9, 1 024: 11.6 / 12.8 / 12.4, 2 048: 20.2 / 21.5 / 19.9, 3 072: 28.9 / 30.0 / 25.8,
+    // 4 096: 37.8 / 39.5 / 32.9 -- below 1 536 bodies the j-parallel form (the block chain's second launch costs more than
+    // the form gains), from there on the block chain (round 1's four launches had put that line at 4 096).
     // Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns the block chain off; NB_STRICT_BC=0/1 decides outright.
-    pl.pc = dbg.strict_pc.or_else((count < 65536u) ? 14u : 0u);
+    constexpr uint32_t kSmallSet = 1536u;
+    pl.pc = dbg.strict_pc.or_else((count < 65536u && n_total >= kSmallSet) ? 14u : 0u);
     if (pl.pc == 1) pl.pc = 8;
     if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
     pl.n_total = n_total;
-    pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= 4096u && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
+    pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= kSmallSet && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     pl.spin_budget = dbg.bc_spin_budget.or_else(0u);
     *out = pl;
