@@ -597,13 +597,19 @@ float rule3_always_bound(float t3)
     return x;
 }
 
-// boids launch shape: the producer/consumer form below 56 K bodies per rank, one lane per body above (NB_BOIDS_PC overrides).
-// Measured at N = 131 072 (tools/sweep.py boidsshard, profiles/r02/boids_forms.log): one lane per body takes 4.65 ms for any
-// shard up to 65 536 bodies (a lone wave per SIMD) and 4.9-5.3 for the whole set; producer/consumer 0.083 ms per 1 024 bodies
-// (16 384: 1.43, 32 768: 2.75, 65 536: 5.41).
-uint32_t boids_use_pc(uint32_t count)
+// boids launch form (nb_kernels.h:launch_boids): 1 = producer/consumer below 45 K bodies per rank; above, one lane per body --
+// form 2, the (x, y) sums and differences as v_pk_* instructions, while the launch has at most one wave per SIMD (up to 65 536
+// bodies: a lone wave is bound by its instruction count), form 0 beyond (two waves per SIMD are bound by lane operations, and
+// there the packed loop is 19 % SLOWER).  Measured at N = 131 072 (tools/sweep.py boidsshard, profiles/r02/boids_forms.log):
+// one lane per body 3.82 ms packed / 4.66 plain for any shard up to 65 536 bodies, 4.9-5.3 plain / 5.85 packed for the whole
+// set; producer/consumer 0.083 ms per 1 024 bodies (16 384: 1.43, 32 768: 2.75, 65 536: 5.41).
+// NB_BOIDS_PC: 1 = producer/consumer, 0 = one lane per body (packing by size), 2 / 3 = one lane per body packed / plain.
+uint32_t boids_form(uint32_t count)
 {
-    return overrides().boids_pc.or_else(count < 57344u ? 1u : 0u);
+    const uint32_t by_size = count <= 65536u ? 2u : 0u;
+    const Knob &k = overrides().boids_pc;
+    if (k.set) return k.v == 1u ? 1u : k.v == 2u ? 2u : k.v == 3u ? 0u : by_size;
+    return count < 46080u ? 1u : by_size;
 }
 
 int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,
@@ -941,7 +947,7 @@ NB_EXPORT int nb_step_boids(nb_ctx *ctx, uint32_t k, const nb_boids_params *para
         a.pos_out = ctx->pos[ctx->cur ^ 1];
         a.vel_in = ctx->vel;
         a.vel_out = ctx->vel_alt;
-        NB_HIP(ctx, nbk::launch_boids(a, tile, boids_use_pc(a.count), ctx->stream));
+        NB_HIP(ctx, nbk::launch_boids(a, tile, boids_form(a.count), ctx->stream));
         ctx->cur ^= 1;
         std::swap(ctx->vel, ctx->vel_alt);
         ctx->steps++;
@@ -1629,7 +1635,7 @@ NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_tot
     a.vel_in = (const float4 *)vel_in;
     a.pos_out = (float4 *)pos_out;
     a.vel_out = (float4 *)vel_out;
-    hipError_t e = nbk::launch_boids(a, tile, boids_use_pc(a.count), (hipStream_t)stream);
+    hipError_t e = nbk::launch_boids(a, tile, boids_form(a.count), (hipStream_t)stream);
     if (e != hipSuccess) {
         g_tls_error = std::string("nb: boids kernel launch failed: ") + hipGetErrorString(e);
         return NB_ERR_HIP;

@@ -214,7 +214,7 @@ def main():
         for f3d in (0, 2):
             for world in (1, 2, 4, 8):
                 count = n_total // world
-                for pc in (0, 1):
+                for pc in (3, 2, 1):  # one lane per body plain / (x, y) packed, producer/consumer
                     os.environ["NB_BOIDS_PC"] = str(pc)
                     nb.reload_env()
                     os.environ["NB_BOIDS_FORCE"] = str(f3d)
@@ -228,7 +228,21 @@ def main():
                         be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / reps
-                    print(f"boids force={f3d} world={world} count={count:7d} pc={pc} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
+                    print(f"boids force={f3d} world={world} count={count:7d} form={pc} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
+        for k in ("NB_BOIDS_PC", "NB_BOIDS_FORCE"):
+            os.environ.pop(k, None)
+        nb.reload_env()
+        for world in (1, 2, 4, 8):  # the library's own choice
+            count = n_total // world
+            for _ in range(2):
+                be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            print(f"boids default world={world} count={count:7d} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
         return
     if what == "configs":
         # the BASELINE.json configurations on one GPU, library defaults
