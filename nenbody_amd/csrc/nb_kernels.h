@@ -41,7 +41,8 @@ struct BoidsArgs {
     uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form, 4 = always test rule 3 (tests)
     uint32_t vlim_bits;    // bit pattern of v_lim: velocity components of at most this magnitude cannot fail the rule-3 test (nb_boids.inc, ALL3)
 };
-// form: 0 = one lane per body, 1 = producer/consumer (64 bodies x 16 waves), 2 = one lane per body with (x, y) packed
+// form: 0 = one lane per body, 1 = producer/consumer (64 bodies x 16 waves), 2 = one lane per body with (x, y) packed,
+// 3 / 4 = chain split (two waves per 64 bodies: rule 1 | rules 2-3) plain / packed
 hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t form, hipStream_t s);
 
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);

@@ -26,13 +26,17 @@ def cloud(oracle, n, seed, scale=0.3):
     return (pos * np.float32(scale)).astype(np.float32), vel
 
 
-@pytest.fixture(params=[(0, 3), (1, 3), (2, 3), (3, 3), (4, 3), (6, 3), (0, 2), (4, 2), (2, 2), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (6, 1)],
+@pytest.fixture(params=[(0, 3), (1, 3), (2, 3), (3, 3), (4, 3), (6, 3), (0, 2), (4, 2), (2, 2), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (6, 1),
+                        (0, 4), (1, 4), (2, 4), (4, 4), (6, 4), (0, 5), (4, 5), (2, 5)],
                 ids=["auto", "select", "masked3d", "select3d", "rule3-tested", "rule3-tested-3d", "packed", "packed-rule3-tested",
-                     "packed-3d-tiles", "pc-auto", "pc-select", "pc-masked3d", "pc-select3d", "pc-rule3-tested", "pc-rule3-tested-3d"])
+                     "packed-3d-tiles", "pc-auto", "pc-select", "pc-masked3d", "pc-select3d", "pc-rule3-tested", "pc-rule3-tested-3d",
+                     "split", "split-select", "split-3d", "split-rule3-tested", "split-rule3-tested-3d", "split-packed",
+                     "split-packed-rule3-tested", "split-packed-3d-tiles"])
 def force(request, monkeypatch):
     """NB_BOIDS_FORCE: OR-ed into every tile's flags -- 1 = never the masked-FMA form, 2 = never the planar form,
     4 = always evaluate the rule-3 test (never the form that knows it holds for the whole tile);
-    NB_BOIDS_PC: the launch form -- one lane per body plain (3) or with (x, y) packed (2), producer/consumer (1).
+    NB_BOIDS_PC: the launch form -- one lane per body plain (3) or with (x, y) packed (2), producer/consumer (1), two waves
+    per body that split the chains, plain (4) or packed (5).
     Every form must give the same bits."""
     monkeypatch.setenv("NB_BOIDS_FORCE", str(request.param[0]))
     monkeypatch.setenv("NB_BOIDS_PC", str(request.param[1]))
@@ -171,7 +175,8 @@ def _rule3_bound(t3):
     return np.array([lo], np.uint32).view(np.float32)[0]
 
 
-@pytest.mark.parametrize("pc", ["3", "2", "1"], ids=["lane-per-body", "lane-per-body-packed", "producer-consumer"])
+@pytest.mark.parametrize("pc", ["3", "2", "1", "4", "5"], ids=["lane-per-body", "lane-per-body-packed", "producer-consumer", "chain-split",
+                                                            "chain-split-packed"])
 @pytest.mark.parametrize("planar", [True, False])
 def test_boids_rule3_known_to_hold_per_tile(nb, oracle, monkeypatch, planar, pc):
     """Tiles whose velocity components all stay within the host's bound skip the rule-3 test (it cannot fail there);

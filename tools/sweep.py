@@ -214,7 +214,7 @@ def main():
         for f3d in (0, 2):
             for world in (1, 2, 4, 8):
                 count = n_total // world
-                for pc in (3, 2, 1):  # one lane per body plain / (x, y) packed, producer/consumer
+                for pc in (3, 2, 1, 4, 5):  # one lane per body plain / (x, y) packed, producer/consumer, chain split plain / packed
                     os.environ["NB_BOIDS_PC"] = str(pc)
                     nb.reload_env()
                     os.environ["NB_BOIDS_FORCE"] = str(f3d)
