@@ -30,13 +30,15 @@ def random_state(rng, n):
     return pos, vel
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(36))
 def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(1000 + case)
     n = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 257, 700, 1500, 2300]))
     k = int(rng.integers(1, 4))
-    shape = rng.choice(["auto", "lanes1", "lanes2", "lanes4", "lanes8", "lanes16", "pc8", "pc14"])
-    if shape.startswith("pc"):
+    shape = rng.choice(["auto", "lanes1", "lanes2", "lanes4", "lanes8", "lanes16", "pc8", "pc14", "bc"])
+    if shape == "bc":
+        monkeypatch.setenv("NB_STRICT_BC", "1")
+    elif shape.startswith("pc"):
         monkeypatch.setenv("NB_STRICT_PC", shape[2:])
     elif shape.startswith("lanes"):
         monkeypatch.setenv("NB_STRICT_PC", "0")
@@ -59,12 +61,13 @@ def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     assert (bits(got_v)[~nanv] == bits(ref_v)[~nanv]).all(), what
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(36))
 def test_boids_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(2000 + case)
     n = int(rng.choice([1, 3, 64, 100, 256, 300, 900, 1300, 2100]))
     k = int(rng.integers(1, 4))
-    monkeypatch.setenv("NB_BOIDS_FORCE", str(int(rng.integers(0, 4))))
+    monkeypatch.setenv("NB_BOIDS_FORCE", str(int(rng.integers(0, 8))))   # select form / never planar / rule 3 always tested
+    monkeypatch.setenv("NB_BOIDS_PC", str(int(rng.integers(0, 6))))      # every launch form (nb_api.hip:boids_form)
     bp, obp = nb.default_boids_params(tile=int(rng.choice([0, 256, 512]))), oracle.boids_params()
     for name, choices in (("rule_1_distance", [1000.0, 50.0, 1e6]), ("rule_2_distance", [5.0, 0.5, 40.0]),
                           ("rule_3_distance", [500.0, 0.3, 2.0]), ("dt", [0.04, 0.5]), ("rule_1_scale", [0.02, -0.01]),
@@ -77,7 +80,7 @@ def test_boids_random_problems_bit_exact(nb, oracle, monkeypatch, case):
         sc.step_boids_n(k, bp)
         got_p, got_v = sc.state()
     ref_p, ref_v = oracle.boids_run(pos, vel, k, obp)
-    what = f"case {case}: n={n} k={k}"
+    what = f"case {case}: n={n} k={k} NB_BOIDS_FORCE={os.environ['NB_BOIDS_FORCE']} NB_BOIDS_PC={os.environ['NB_BOIDS_PC']}"
     nan = np.isnan(ref_p)
     assert (np.isnan(got_p) == nan).all(), what
     assert (bits(got_p)[~nan] == bits(ref_p)[~nan]).all(), what
