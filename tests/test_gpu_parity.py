@@ -432,6 +432,61 @@ def test_every_rank_shape_of_configs_4_and_5_vs_oracle(nb, oracle, n, world):
     assert np.abs(pf - pf1).max() <= dv_all.max() + ulp_p, msg
 
 
+def test_shards_of_a_four_million_body_set_vs_oracle(nb, oracle):
+    """Index arithmetic past 2^22: ragged shards of a 4 194 341-body set through the launch API -- a block-chain shard near the
+    front, a one-lane-per-body shard that ends at the last body, the boids controller on a producer/consumer shard and on a
+    chain-split shard -- against the oracle on sampled bodies (first, last, inside), STRICT and boids bit for bit."""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    n = (1 << 22) + 37
+    pos, vel = nb.init_state(n, 4242)
+    parts = [(5, 4099), (n - 70001, 70001)]
+    ps, vs = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(), 1)
+    off = 0
+    for first, count in parts:
+        for i in sorted({first, first + 1, first + count // 3, first + count - 2, first + count - 1}):
+            p_ref, v_ref = oracle.step_range(pos, vel[i:i + 1], int(i), 1)
+            assert (bits(ps[i]) == bits(p_ref[0])).all(), f"STRICT position of body {i} (shard {first}+{count})"
+            assert (bits(vs[off + i - first]) == bits(v_ref[0])).all(), f"STRICT velocity of body {i} (shard {first}+{count})"
+        off += count
+    # FAST on the same shards.  At 4e6 terms the reference's own sequential binary32 sum is ~1e-3 of the velocity change away
+    # from the sum carried in binary64, so FAST is held to being no further from THAT sum than the reference's arithmetic is
+    # (plus its stated per-step tolerance), as in the 2^20-body test above.
+    pf, vf = _sharded_step_on_one_gpu(nb, pos, vel, parts, nb.default_params(mode=nb.NB_MODE_FAST), 1)
+    c = [float(np.float32(x)) for x in (0.1, 0.001, 0.0000001)]
+    off = 0
+    for first, count in parts:
+        idx = np.array(sorted({first, first + count // 2, first + count - 1}))
+        refs = np.concatenate([oracle.step_range(pos, vel[i:i + 1], int(i), 1)[1] for i in idx])
+        dv64 = np.concatenate([oracle.step_range_dv_f64(pos, int(i), 1, *c) for i in idx])
+        v_true = vel[idx].astype(np.float64) + dv64
+        scale = np.abs(dv64).max()
+        err_ref = np.abs(refs.astype(np.float64) - v_true).max()
+        err_fast = np.abs(vf[off + idx - first].astype(np.float64) - v_true).max()
+        assert err_fast <= err_ref + 2e-5 * scale, f"FAST shard {first}+{count}: {err_fast / scale:.2e} against the reference's {err_ref / scale:.2e}"
+        off += count
+    # boids: a producer/consumer shard and a chain-split shard
+    be, dev = HipBackend(), torch.device("cuda", 0)
+
+    def rec(a):
+        t = torch.zeros((n, 4))
+        t[:, :3] = torch.from_numpy(a)
+        return t.to(dev)
+
+    pin, vin = rec(pos), rec(vel)
+    pout, vout = torch.zeros_like(pin), torch.zeros_like(vin)
+    bp, obp = nb.default_boids_params(), oracle.boids_params()
+    for first, count in ((11, 5000), (n - 50000, 50000)):
+        be.boids_step(bp, n, first, count, pin, vin, pout, vout)
+        torch.cuda.synchronize()
+        for i in sorted({first, first + count // 2, first + count - 1}):
+            p_ref, v_ref = oracle.boids_step_range(pos, vel, int(i), 1, obp)
+            got_p, got_v = pout[i, :3].cpu().numpy(), vout[i, :3].cpu().numpy()
+            assert (bits(got_p) == bits(p_ref[0])).all() and (bits(got_v) == bits(v_ref[0])).all(), f"boids body {i} (shard {first}+{count})"
+
+
 def test_fast_full_size_close_to_strict_and_shard_consistent(nb):
     n = 131072
     pos, vel = nb.init_state(n, 1234)
