@@ -135,8 +135,13 @@ int nb_device_state(nb_ctx *ctx, const void **pos_rec, const void **vel_rec, con
 
 /* CameraArray::update (src/gfx.rs:397-408, build_camera :358-369) for the context's current state: per body
  * out = cp * look_at_dir(eye = position, dir = velocity, up), where cp16 = OPENGL_TO_WGPU_MATRIX * perspective(...) is the
- * array's constant (16 floats, column-major; the caller's cgmath::perspective keeps its tan()).  out_16n: host, 16n floats. */
+ * array's constant (16 floats, column-major; nb_camera_constant below, or the caller's own cgmath::perspective).  out_16n: host, 16n floats. */
 int nb_cameras(nb_ctx *ctx, const float *up_xyz, const float *cp16, float *out_16n);
+
+/* That constant: cp16 = OPENGL_TO_WGPU_MATRIX * cgmath::perspective(Deg(vertical_fov_deg), aspect_ratio, near, far), 16 floats,
+ * column-major (src/gfx.rs:12-17, 365, 367; the reference passes near = 1, far = 10000 and vertical_fov = horizontal_fov /
+ * aspect_ratio, src/gfx.rs:381).  Host arithmetic, no device needed; NB_ERR_INVALID where cgmath's assertions would panic. */
+int nb_camera_constant(float vertical_fov_deg, float aspect_ratio, float near_plane, float far_plane, float *cp16);
 
 /* Device -> host, after waiting for queued steps.  Any of the three may be NULL.
  * inst_16n, when given, receives the model matrices of the current state (src/main.rs:437-439),

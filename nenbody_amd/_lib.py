@@ -86,6 +86,7 @@ PROTOTYPES = {
     "nb_step_random": (c_int, [c_void_p, c_uint32, c_uint64]),
     "nb_device_state": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "nb_cameras": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_camera_constant": (c_int, [ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p]),
     "nb_launch_cameras": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "nb_update_instance_nbody": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbParams)]),

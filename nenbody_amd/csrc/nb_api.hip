@@ -994,6 +994,39 @@ NB_EXPORT int nb_device_state(nb_ctx *ctx, const void **pos_rec, const void **ve
     return NB_OK;
 }
 
+// The constant of a camera array: OPENGL_TO_WGPU_MATRIX * perspective(vertical_fov, aspect, near, far) (src/gfx.rs:12-17, 365,
+// 367).  Host arithmetic only (one tanf per ARRAY, not per entity): cgmath 0.17's Deg -> Rad (deg * PI/180, the constant
+// formed in binary64), PerspectiveFov -> Matrix4 (f = 1 / tan(fovy / 2); f / aspect, f, (far + near) / (near - far), -1,
+// (2 far near) / (near - far)) and Matrix4 * Matrix4 (((a r0 + b r1) + c r2) + d r3 per entry), its assertions as an error.
+NB_EXPORT int nb_camera_constant(float vertical_fov_deg, float aspect_ratio, float near_plane, float far_plane, float *cp16)
+{
+    if (!cp16) {
+        g_tls_error = "nb_camera_constant: cp16 is null";
+        return NB_ERR_INVALID;
+    }
+    const float pi = (float)3.14159265358979323846;
+    const float fovy = vertical_fov_deg * (float)(3.14159265358979323846 / 180.0);
+    if (!(fovy > 0.0f) || !(fovy < pi) || !(aspect_ratio != 0.0f) || !(near_plane > 0.0f) || !(far_plane > 0.0f) || !(far_plane != near_plane)) {
+        g_tls_error = "nb_camera_constant: cgmath::perspective asserts 0 < fovy < 180 degrees, aspect != 0, near > 0, far > 0, far != near";
+        return NB_ERR_INVALID;
+    }
+    const float f = 1.0f / std::tan(fovy / 2.0f);
+    float proj[16] = {0.0f};  // column-major
+    proj[0] = f / aspect_ratio;
+    proj[5] = f;
+    proj[10] = (far_plane + near_plane) / (near_plane - far_plane);
+    proj[11] = -1.0f;
+    proj[14] = ((2.0f * far_plane) * near_plane) / (near_plane - far_plane);
+    const float corr[16] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.5f, 1.0f};  // src/gfx.rs:12-17
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) {
+            const float t0 = corr[row] * proj[4 * col], t1 = corr[4 + row] * proj[4 * col + 1];
+            const float t2 = corr[8 + row] * proj[4 * col + 2], t3 = corr[12 + row] * proj[4 * col + 3];
+            cp16[4 * col + row] = ((t0 + t1) + t2) + t3;
+        }
+    return NB_OK;
+}
+
 NB_EXPORT int nb_cameras(nb_ctx *ctx, const float *up_xyz, const float *cp16, float *out_16n)
 {
     if (!ctx) {

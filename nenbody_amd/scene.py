@@ -30,6 +30,15 @@ def _as_f32(a, shape_tail, name):
     return arr
 
 
+def camera_constant(vertical_fov_deg: float, aspect_ratio: float, near: float = 1.0, far: float = 10000.0) -> np.ndarray:
+    """The constant of a camera array, OPENGL_TO_WGPU_MATRIX * cgmath::perspective(...) (src/gfx.rs:12-17, 365, 367), as the
+    (4, 4) array ``Scene.cameras`` takes ([k] = column k).  The reference's CameraArray::new derives the vertical field of view
+    as horizontal_fov / aspect_ratio (src/gfx.rs:381) and build_camera passes near = 1, far = 10000."""
+    cp = np.zeros((4, 4), np.float32)
+    check(_lib.load().nb_camera_constant(vertical_fov_deg, aspect_ratio, near, far, cp.ctypes.data))
+    return cp
+
+
 def init_state(n: int, seed: int = 1234):
     """Seeded stand-in for the reference's unseeded initial state (src/main.rs:736-747).
 

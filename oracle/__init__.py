@@ -232,6 +232,18 @@ def cameras(eyes, dirs, up, cp):
     return out
 
 
+def camera_constant(vertical_fov_deg: float, aspect: float, near: float = 1.0, far: float = 10000.0):
+    """OPENGL_TO_WGPU_MATRIX * cgmath::perspective(...) of build_camera (gfx.rs:365-367) as a (4, 4) array whose [k] is
+    column k; raises ValueError where cgmath would panic."""
+    cp = np.zeros((4, 4), np.float32)
+    lib = load()
+    lib.nbo_camera_constant.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    lib.nbo_camera_constant.restype = ctypes.c_int
+    if lib.nbo_camera_constant(vertical_fov_deg, aspect, near, far, cp.ctypes.data) != 0:
+        raise ValueError("perspective: arguments cgmath asserts against")
+    return cp
+
+
 def random_run(pos, vel, k: int, seed: int, first_step: int = 0, want_instances: bool = False):
     """k applications of update_instance_random (main.rs:381-402) with the build-owned counter-based stream."""
     p = np.ascontiguousarray(pos, np.float32).copy()

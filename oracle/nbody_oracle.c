@@ -491,6 +491,36 @@ NBO_API void nbo_cameras(const float *eye3, const float *dir3, const float *up3,
     }
 }
 
+/* The array's constant  OPENGL_TO_WGPU_MATRIX * perspective(vertical_fov, aspect, near, far)  of build_camera
+ * (src/gfx.rs:365, 367; OPENGL_TO_WGPU_MATRIX src/gfx.rs:12-17; the reference passes near = 1, far = 10000 and, from
+ * CameraArray::new src/gfx.rs:381, vertical_fov = horizontal_fov / aspect_ratio).  cgmath 0.17 restated:
+ *   Deg -> Rad: deg * (PI / 180) with the constant formed in binary64 and cast;  perspective(fovy, aspect, near, far) =
+ *   PerspectiveFov -> Matrix4: f = cot(fovy / 2) = 1 / tan(fovy / 2);  c0r0 = f / aspect, c1r1 = f,
+ *   c2r2 = (far + near) / (near - far), c2r3 = -1, c3r2 = (2 * far * near) / (near - far), every other entry 0.
+ * Returns 0, or -1 where cgmath's assertions would panic (fovy outside (0, 180) degrees, aspect == 0, near <= 0, far <= near...). */
+NBO_API int nbo_camera_constant(float vertical_fov_deg, float aspect, float near, float far, float *cp16)
+{
+    const float fovy = vertical_fov_deg * (float)(3.14159265358979323846 / 180.0);
+    if (!(fovy > 0.0f) || !(fovy < (float)3.14159265358979323846) || !(aspect != 0.0f) || !(near > 0.0f) || !(far > 0.0f) ||
+        !(far != near))
+        return -1;
+    const float f = 1.0f / tanf(fovy / 2.0f);
+    float proj[4][4] = {{0}};  /* proj[k] = column k */
+    proj[0][0] = f / aspect;
+    proj[1][1] = f;
+    proj[2][2] = (far + near) / (near - far);
+    proj[2][3] = -1.0f;
+    proj[3][2] = ((2.0f * far) * near) / (near - far);
+    static const float corr[4][4] = {{1.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.5f, 0.0f}, {0.0f, 0.0f, 0.5f, 1.0f}};
+    for (int k = 0; k < 4; ++k)
+        for (int e = 0; e < 4; ++e) {
+            const float t0 = corr[0][e] * proj[k][0], t1 = corr[1][e] * proj[k][1];
+            const float t2 = corr[2][e] * proj[k][2], t3 = corr[3][e] * proj[k][3];
+            cp16[4 * k + e] = ((t0 + t1) + t2) + t3;
+        }
+    return 0;
+}
+
 /* ====================================================================================
  * Random-walk controller: update_instance_random, src/main.rs:381-402.
  *   vel += (U[-0.0001, 0.0001), U[-0.0001, 0.0001), 0);  pos += vel;  matrix as above.

@@ -302,3 +302,35 @@ def test_committed_hbm_traffic_is_of_the_current_kernel_sources(nb):
     if t["src_sha"] != _lib.kernel_source_sha():
         pytest.skip("profiles/hbm_traffic.json is stale (kernel sources changed since the PMC passes): re-run tools/profile_bench.sh "
                     "and tools/pmc_summary.py --json")
+
+
+def test_camera_constant_is_host_arithmetic_and_matches_the_oracle(oracle):
+    """nb_camera_constant = OPENGL_TO_WGPU_MATRIX * cgmath::perspective (gfx.rs:12-17, 365-367): no device needed; the C
+    restatement in the oracle gives the same bits, an independent numpy restatement the same values, and cgmath's
+    assertions come back as NB_ERR_INVALID."""
+    import nenbody_amd as nb
+    from nenbody_amd import _lib
+
+    for fov, aspect, near, far in ((45.0, 16 / 9, 1.0, 10000.0), (90.0 / (4 / 3), 4 / 3, 1.0, 10000.0), (25.3125, 1.0, 0.5, 77.0),
+                                   (179.0, 2.0, 1e-3, 1e6)):
+        got = nb.camera_constant(fov, aspect, near, far)
+        ref = oracle.camera_constant(fov, aspect, near, far)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), (fov, aspect, near, far)
+        f = 1.0 / np.tan(np.deg2rad(np.float32(fov), dtype=np.float64) / 2)
+        want = np.zeros((4, 4))                      # [k] = column k of correction * proj
+        want[0, 0] = f / aspect
+        want[1, 1] = f
+        want[2, 2] = 0.5 * (far + near) / (near - far) - 0.5
+        want[2, 3] = -1.0
+        want[3, 2] = 0.5 * 2 * far * near / (near - far)
+        if fov < 170:                                # near 180 degrees tan is ill-conditioned in the binary32 half-angle
+            assert np.allclose(got, want, rtol=2e-6, atol=0), (got, want)
+    cp = np.zeros(16, np.float32)
+    lib = nb.load()
+    for bad in ((0.0, 1.0, 1.0, 10.0), (180.0, 1.0, 1.0, 10.0), (-5.0, 1.0, 1.0, 10.0), (45.0, 0.0, 1.0, 10.0), (45.0, 1.0, 0.0, 10.0),
+                (45.0, 1.0, 1.0, 1.0), (45.0, 1.0, 1.0, -3.0), (float("nan"), 1.0, 1.0, 10.0)):
+        assert lib.nb_camera_constant(*bad, cp.ctypes.data) == _lib.NB_ERR_INVALID, bad
+        assert "perspective" in _lib.last_error()
+        with pytest.raises(ValueError):
+            oracle.camera_constant(*bad)
+    assert lib.nb_camera_constant(45.0, 1.0, 1.0, 10.0, None) == _lib.NB_ERR_INVALID

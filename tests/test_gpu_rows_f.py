@@ -29,6 +29,11 @@ def perspective_cp(fovy_deg=45.0, aspect=16 / 9, near=1.0, far=10000.0):
     return cp.astype(np.float32)
 
 
+def test_camera_constant_of_the_library_is_the_callers(nb):
+    """nb_camera_constant against the restatement above (numpy's tan in binary64, so values, not bits)"""
+    assert np.allclose(nb.camera_constant(45.0, 16 / 9), perspective_cp(), rtol=2e-6, atol=0)
+
+
 def test_cameras_bit_exact(nb, oracle):
     n = 3000
     pos, vel = oracle.init_state(n, 11)
@@ -38,6 +43,7 @@ def test_cameras_bit_exact(nb, oracle):
     cp = perspective_cp()
     with nb.Scene(pos, vel) as sc:
         got = sc.cameras(up, cp)
+        assert (bits(sc.cameras(up, nb.camera_constant(30.0, 1.5))) == bits(oracle.cameras(pos, vel, up, oracle.camera_constant(30.0, 1.5)))).all()
         sc.step_n(2)
         got2 = sc.cameras(up, cp)
         p2, v2 = sc.state()
