@@ -53,7 +53,7 @@ for n in (100, 256, 512, 1024, 2048, 3072, 4096, 8192):
     if "fast" in what:
         for env in ({}, {"NB_FAST_WAVES": 0}, {"NB_FAST_WAVES": 4}, {"NB_FAST_WAVES": 8, "NB_FAST_IB": 2}, {"NB_FAST_WAVES": 8, "NB_FAST_SLICES": 1},
                     {"NB_FAST_WAVES": 8, "NB_FAST_SLICES": 2}, {"NB_FAST_WAVES": 8, "NB_FAST_SLICES": 4}):
-            timed(n, dict(env, mode="fast") if False else env, nbody(nb.NB_MODE_FAST))
+            timed(n, env, nbody(nb.NB_MODE_FAST))
     if "boids" in what:
         for env in ({}, {"NB_BOIDS_PC": 3}, {"NB_BOIDS_PC": 2}, {"NB_BOIDS_PC": 1}):
             timed(n, env, boids, steps=1000)
