@@ -205,7 +205,7 @@ int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
 
 /* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
  * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
- * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_SHARD_RCCL_SOLO, and NB_ROCTX = 1: roctx ranges
+ * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_SHARD_RCCL_SOLO, NB_DROPIN_ZERO_COPY, and NB_ROCTX = 1: roctx ranges
  * around the step loops and the exchange, for rocprofv3 --marker-trace) are read ONCE per process, at first use; no launch
  * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
  * and shards keep the launch shape chosen when they were created. */

@@ -43,7 +43,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo, roctx;
+        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -83,6 +83,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_pc = read_knob("NB_BOIDS_PC");
     d->boids_tile = read_knob("NB_BOIDS_TILE");
     d->boids_force = read_knob("NB_BOIDS_FORCE");
+    d->dropin_zero_copy = read_knob("NB_DROPIN_ZERO_COPY");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
     d->shard_rccl_solo = read_knob("NB_SHARD_RCCL_SOLO");
     d->roctx = read_knob("NB_ROCTX");
@@ -706,6 +707,7 @@ struct nb_ctx {
     float4 *cams = nullptr;   // 4n float4, allocated on first use (nb_cameras)
     float *xfer = nullptr;    // 22n floats [matrices 16n | positions 3n | velocities 3n]: one-copy round trip of the drop-in calls
     float *hxfer = nullptr;   // its pinned host twin
+    float *hxfer_dev = nullptr;  // the device's address of hxfer (mapped host memory: kernels of the small-set drop-in read and write it directly)
     void *scratch = nullptr;
     StatusWord status;        // sticky failure word of this context's block-chain launches
     int cur = 0;
@@ -791,12 +793,20 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
 // Sets up to this size cross the bus as ONE pinned copy each way (they are all latency: every separate copy and wait
 // shows); larger sets are all bandwidth and copy straight from / to the caller's arrays.  Measured: tools/crossover.py.
 constexpr uint32_t kRoundtripMax = 16384;
+// Small sets: the pack / unpack kernels read and write the pinned host buffer through the bus themselves instead of a DMA copy
+// each way -- 7-14 us less per call at every size up to kRoundtripMax (tools/dropin_small.py, profiles/r02/dropin_small.log:
+// N = 100 32.6 -> 25.6 us, N = 2 048 66.7 -> 52.8, N = 16 384 240 -> 226).  NB_DROPIN_ZERO_COPY=0 stages through DMA copies.
+constexpr uint32_t kZeroCopyMax = kRoundtripMax;
+static bool small_set_zero_copy(uint32_t n) { return overrides().dropin_zero_copy.or_else(n <= kZeroCopyMax ? 1u : 0u) != 0u; }
 
 static int ensure_xfer(nb_ctx *c)
 {
     const size_t bytes = ((size_t)c->n * 22 + 16) * sizeof(float);  // + a tail word: the status word rides along (update_roundtrip)
     if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, bytes));
-    if (!c->hxfer) NB_HIP(c, hipHostMalloc((void **)&c->hxfer, bytes, hipHostMallocDefault));
+    if (!c->hxfer) {
+        NB_HIP(c, hipHostMalloc((void **)&c->hxfer, bytes, hipHostMallocMapped));
+        NB_HIP(c, hipHostGetDevicePointer((void **)&c->hxfer_dev, c->hxfer, 0));
+    }
     return NB_OK;
 }
 
@@ -871,8 +881,12 @@ NB_EXPORT int nb_upload(nb_ctx *ctx, const float *pos_xyz, const float *vel_xyz)
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a download still reading hxfer must be done (it always is: downloads wait)
         std::memcpy(ctx->hxfer, pos_xyz, bytes);
         std::memcpy(ctx->hxfer + 3 * (size_t)ctx->n, vel_xyz, bytes);
-        NB_HIP(ctx, hipMemcpyAsync(ctx->xfer, ctx->hxfer, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
-        NB_HIP(ctx, nbk::launch_import(ctx->n, ctx->xfer, ctx->xfer + 3 * (size_t)ctx->n, ctx->pos[0], ctx->vel, ctx->stream));
+        float *src = ctx->hxfer_dev;  // the kernel reads the pinned buffer through the bus ...
+        if (!small_set_zero_copy(ctx->n)) {  // ... or a DMA copy stages it in device memory first
+            NB_HIP(ctx, hipMemcpyAsync(ctx->xfer, ctx->hxfer, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
+            src = ctx->xfer;
+        }
+        NB_HIP(ctx, nbk::launch_import(ctx->n, src, src + 3 * (size_t)ctx->n, ctx->pos[0], ctx->vel, ctx->stream));
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // hxfer / xfer are reused by the next call
         ctx->uploaded = true;
         ctx->steps = 0;
@@ -1075,10 +1089,14 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         int rc = ensure_xfer(ctx);
         if (rc != NB_OK) return rc;
         const size_t n = ctx->n;
-        NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)ctx->xfer : nullptr,
-                                       pos_xyz ? ctx->xfer + 16 * n : nullptr, vel_xyz ? ctx->xfer + 19 * n : nullptr, ctx->stream));
-        const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
-        NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        const bool zero_copy = small_set_zero_copy(ctx->n);
+        float *const dst = zero_copy ? ctx->hxfer_dev : ctx->xfer;
+        NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)dst : nullptr,
+                                       pos_xyz ? dst + 16 * n : nullptr, vel_xyz ? dst + 19 * n : nullptr, ctx->stream));
+        if (!zero_copy) {
+            const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
+            NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        }
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (inst_16n) std::memcpy(inst_16n, ctx->hxfer, n * 16 * sizeof(float));
         if (pos_xyz) std::memcpy(pos_xyz, ctx->hxfer + 16 * n, bytes);
@@ -1146,15 +1164,23 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
     c->cur = 0;
     c->uploaded = true;
     c->steps = 0;
-    NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
-    NB_HIP(c, nbk::launch_import(c->n, c->xfer, c->xfer + 3 * n, c->pos[0], c->vel, c->stream));
+    // the pack / unpack kernels read and write the pinned host buffer THROUGH THE BUS themselves: the two DMA operations of a
+    // staged copy cost more in fixed latency than these few kilobytes cost in bandwidth (kZeroCopyMax)
+    const bool zero_copy = small_set_zero_copy(c->n);
+    float *const in = zero_copy ? c->hxfer_dev : c->xfer, *const out = zero_copy ? c->hxfer_dev : c->xfer;
+    if (!zero_copy) NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
+    NB_HIP(c, nbk::launch_import(c->n, in, in + 3 * n, c->pos[0], c->vel, c->stream));
     rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
     if (rc != NB_OK) return rc;
-    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)c->xfer, c->xfer + 16 * n, c->xfer + 19 * n, c->stream));
+    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, c->stream));
     // the sticky status word of this context's block-chain launches comes home in the same copy: no second wait per frame
     const bool with_status = c->status.dirty && c->status.w;
-    if (with_status) NB_HIP(c, hipMemcpyAsync(c->xfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (zero_copy) {
+        if (with_status) NB_HIP(c, hipMemcpyAsync(c->hxfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (with_status) NB_HIP(c, hipMemcpyAsync(c->xfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     NB_HIP(c, hipStreamSynchronize(c->stream));
     if (with_status) {
         uint32_t v;

@@ -756,6 +756,35 @@ def test_update_instance_nbody_matches_reference_semantics(nb, oracle):
     assert (inst[:, 3, :3] == positions).all()       # translation column is the new position, exactly
 
 
+@pytest.mark.parametrize("zero_copy", ["1", "0"], ids=["kernels-touch-pinned-host-memory", "staged-by-dma-copies"])
+@pytest.mark.parametrize("n", [100, 2048, 5000])
+def test_small_set_transfers_both_ways(nb, oracle, monkeypatch, zero_copy, n):
+    """Sets of up to 16 384 bodies cross the bus through one pinned buffer; by default the pack / unpack kernels read and write
+    it through the bus themselves, NB_DROPIN_ZERO_COPY=0 stages it with a DMA copy each way.  Same results either way, in the
+    drop-in calls (n-body over frames, boids) and in Scene's upload / step / download."""
+    monkeypatch.setenv("NB_DROPIN_ZERO_COPY", zero_copy)
+    pos, vel = state3d(oracle, n, seed=300 + n)
+    p_ref, v_ref, inst_ref = oracle.run(pos, vel, 2, want_instances=True)
+    p, v = pos.copy(), vel.copy()
+    op, ov, inst = np.zeros_like(p), np.zeros_like(v), np.zeros((n, 4, 4), np.float32)
+    for _ in range(2):
+        nb.update_instance_nbody(inst, p, op, v, ov)
+    assert_bits_equal(p, p_ref)
+    assert_bits_equal(v, v_ref)
+    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    pb, vb = pos.copy(), vel.copy()
+    nb.update_instance_boids(inst, pb, op, vb, ov)
+    pb_ref, vb_ref = oracle.boids_run(pos, vel, 1)
+    assert_bits_equal(pb, pb_ref)
+    assert_bits_equal(vb, vb_ref)
+    with nb.Scene(pos, vel) as sc:
+        sc.step()
+        sc.step()
+        assert_bits_equal(sc.positions(), p_ref)
+        assert_bits_equal(sc.velocities(), v_ref)
+        assert np.allclose(sc.instances(), inst_ref, rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("n,m", [(200, 50), (20000, 70)])   # both transfer paths of the drop-in call (small / large sets)
 def test_update_instance_nbody_zip_truncation(nb, oracle, n, m):
     """instances shorter than positions: only that many bodies move, the fold still sees everyone (main.rs:420-425)."""
