@@ -799,6 +799,19 @@ constexpr uint32_t kRoundtripMax = 16384;
 constexpr uint32_t kZeroCopyMax = kRoundtripMax;
 static bool small_set_zero_copy(uint32_t n) { return overrides().dropin_zero_copy.or_else(n <= kZeroCopyMax ? 1u : 0u) != 0u; }
 
+// after a small-set export whose kernel copied the status word behind the 22n floats of hxfer (and the wait)
+static int status_from_tail(nb_ctx *c, bool with_status)
+{
+    if (!with_status) return NB_OK;
+    uint32_t v;
+    std::memcpy(&v, c->hxfer + 22 * (size_t)c->n, sizeof(v));
+    if (v == 0u) {
+        c->status.dirty = false;
+        return NB_OK;
+    }
+    return check_status(&c->status, &c->err);  // reads it again, clears it, reports NB_ERR_STATE
+}
+
 static int ensure_xfer(nb_ctx *c)
 {
     const size_t bytes = ((size_t)c->n * 22 + 16) * sizeof(float);  // + a tail word: the status word rides along (update_roundtrip)
@@ -1091,17 +1104,20 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         const size_t n = ctx->n;
         const bool zero_copy = small_set_zero_copy(ctx->n);
         float *const dst = zero_copy ? ctx->hxfer_dev : ctx->xfer;
+        // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait
+        const bool with_status = ctx->status.dirty && ctx->status.w;
         NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)dst : nullptr,
-                                       pos_xyz ? dst + 16 * n : nullptr, vel_xyz ? dst + 19 * n : nullptr, ctx->stream));
+                                       pos_xyz ? dst + 16 * n : nullptr, vel_xyz ? dst + 19 * n : nullptr,
+                                       with_status ? ctx->status.w : nullptr, with_status ? (uint32_t *)(dst + 22 * n) : nullptr, ctx->stream));
         if (!zero_copy) {
-            const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
+            const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = with_status ? 22 * n + 1 : vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
             NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         }
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (inst_16n) std::memcpy(inst_16n, ctx->hxfer, n * 16 * sizeof(float));
         if (pos_xyz) std::memcpy(pos_xyz, ctx->hxfer + 16 * n, bytes);
         if (vel_xyz) std::memcpy(vel_xyz, ctx->hxfer + 19 * n, bytes);
-        return check_status(&ctx->status, &ctx->err);
+        return status_from_tail(ctx, with_status);
     }
     if (pos_xyz) {
         NB_HIP(ctx, nbk::launch_unpack(ctx->n, ctx->pos[ctx->cur], ctx->stage, ctx->stream));
@@ -1172,24 +1188,15 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
     NB_HIP(c, nbk::launch_import(c->n, in, in + 3 * n, c->pos[0], c->vel, c->stream));
     rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
     if (rc != NB_OK) return rc;
-    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, c->stream));
-    // the sticky status word of this context's block-chain launches comes home in the same copy: no second wait per frame
+    // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait per frame
     const bool with_status = c->status.dirty && c->status.w;
-    if (zero_copy) {
-        if (with_status) NB_HIP(c, hipMemcpyAsync(c->hxfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    } else {
-        if (with_status) NB_HIP(c, hipMemcpyAsync(c->xfer + 22 * n, c->status.w, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, with_status ? c->status.w : nullptr,
+                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream));
+    if (!zero_copy)
         NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    }
     NB_HIP(c, hipStreamSynchronize(c->stream));
-    if (with_status) {
-        uint32_t v;
-        std::memcpy(&v, c->hxfer + 22 * n, sizeof(v));
-        if (v == 0u)
-            c->status.dirty = false;
-        else
-            return check_status(&c->status, &c->err);  // reads it again, clears it, reports NB_ERR_STATE
-    }
+    rc = status_from_tail(c, with_status);
+    if (rc != NB_OK) return rc;
     std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));
     std::memcpy(pos_out, c->hxfer + 16 * n, count * xyz);
     std::memcpy(vel_out, c->hxfer + 19 * n, count * xyz);

@@ -78,6 +78,6 @@ hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStrea
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each
 hipError_t launch_import(uint32_t count, const float *pos_xyz, const float *vel_xyz, float4 *pos_rec, float4 *vel_rec, hipStream_t s);
 hipError_t launch_export(uint32_t count, const float4 *pos_rec, const float4 *vel_rec, float4 *inst, float *pos_xyz, float *vel_xyz,
-                         hipStream_t s);
+                         const uint32_t *status_src, uint32_t *status_dst, hipStream_t s);
 
 }  // namespace nbk

@@ -1110,6 +1110,15 @@ def test_block_chain_give_up_is_reported_as_an_error(nb, oracle, monkeypatch):
         with pytest.raises(nb.NbError) as e:
             sc.state()
         assert e.value.status == _lib.NB_ERR_STATE
+    # the one-call drop-in: the status word rides home in its transfer buffer (written there by the unpack kernel, or staged)
+    for zero_copy in ("1", "0"):
+        monkeypatch.setenv("NB_DROPIN_ZERO_COPY", zero_copy)
+        p, v = pos.copy(), vel.copy()
+        with pytest.raises(nb.NbError) as e:
+            nb.update_instance_nbody(np.zeros((n, 4, 4), np.float32), p, np.zeros_like(p), v, np.zeros_like(v))
+        assert e.value.status == _lib.NB_ERR_STATE, zero_copy
+    monkeypatch.delenv("NB_DROPIN_ZERO_COPY")
+    nb.update_release()
     # launch API: nb_launch_status
     import torch
 
