@@ -599,20 +599,20 @@ float rule3_always_bound(float t3)
 }
 
 // boids launch form (nb_kernels.h:launch_boids), by bodies per rank.  Measured at N = 131 072 (tools/sweep.py boidsshard,
-// profiles/r02/boids_forms.log), ms per step for shards of 16 384 / 32 768 / 65 536 / 131 072 bodies:
-//   1  producer/consumer                      1.43 / 2.72 / 5.39 / 10.8   (0.083 ms per 1 024 bodies)
-//   3  chain split, two waves per 64 bodies   3.54 / 3.53 / 3.56 / 7.17   (flat while the launch fits the chip once)
-//   2  one lane per body, (x, y) packed       3.84 / 3.87 / 3.86 / 5.79   (a lone wave per SIMD is bound by its instruction count)
-//   0  one lane per body                      4.81 / 4.82 / 4.84 / 4.96-5.3 (two waves per SIMD are bound by lane operations)
-//   4  chain split packed                     3.88 / 3.90 / 3.91 / 7.85
-// so: producer/consumer below 42 K bodies, chain split up to 88 K, one lane per body above.
+// profiles/r02/boids_forms.log), ms per step for shards of 16 384 / 32 768 / 49 152 / 65 536 / 131 072 bodies:
+//   1  producer/consumer                      1.43 / 2.28 / 3.44 / 4.14 / 8.0   (rounds of 512 workgroups of 64 bodies: steps, not a line)
+//   3  chain split, two waves per 64 bodies   3.54 / 3.53 / 3.54 / 3.56 / 7.17  (one round of 256 workgroups up to 65 536 bodies; 7.3 beyond)
+//   2  one lane per body, (x, y) packed       3.84 / 3.87 / 3.86 / 3.86 / 5.79  (a lone wave per SIMD is bound by its instruction count)
+//   0  one lane per body                      4.81 / 4.82 / 4.83 / 4.84 / 4.96-5.3 (two waves per SIMD are bound by lane operations)
+//   4  chain split packed                     3.88 / 3.90 / 3.90 / 3.91 / 7.85
+// so: producer/consumer up to 48 K bodies, chain split up to 64 K, one lane per body above.
 // NB_BOIDS_PC: 1 = producer/consumer, 2 / 3 = one lane per body packed / plain, 4 / 5 = chain split plain / packed,
 // 0 = one lane per body, packed while the launch has at most one wave per SIMD.
 uint32_t boids_form(uint32_t count)
 {
     const Knob &k = overrides().boids_pc;
     if (k.set) return k.v == 1u ? 1u : k.v == 2u ? 2u : k.v == 3u ? 0u : k.v == 4u ? 3u : k.v == 5u ? 4u : (count <= 65536u ? 2u : 0u);
-    return count < 43008u ? 1u : count <= 90112u ? 3u : 0u;
+    return count <= 49152u ? 1u : count <= 65536u ? 3u : 0u;
 }
 
 int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, uint32_t count, nbk::BoidsArgs *out,

@@ -232,8 +232,8 @@ def main():
         for k in ("NB_BOIDS_PC", "NB_BOIDS_FORCE"):
             os.environ.pop(k, None)
         nb.reload_env()
-        for world in (1, 2, 4, 8):  # the library's own choice
-            count = n_total // world
+        for count in (131072, 98304, 90112, 81920, 65536, 57344, 53248, 49152, 40960, 32768, 16384):  # the library's own choice
+            world = n_total / count
             for _ in range(2):
                 be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
             torch.cuda.synchronize()
@@ -242,7 +242,7 @@ def main():
                 be.boids_step(bp, n_total, 0, count, pin, vin, pout, vout)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 5
-            print(f"boids default world={world} count={count:7d} ms={dt * 1e3:8.3f} x{world}={dt * 1e3 * world:7.2f}", flush=True)
+            print(f"boids default count={count:7d} ms={dt * 1e3:8.3f} x{world:.2f}={dt * 1e3 * world:7.2f}", flush=True)
         return
     if what == "configs":
         # the BASELINE.json configurations on one GPU, library defaults
