@@ -1,6 +1,6 @@
 #!/bin/bash
 # profile_bench.sh OUTDIR -- the rocprofv3 evidence of one round, run on the GPU box from the repo root:
-#   OUTDIR/stats_{strict,fast}  rocprofv3 --kernel-trace --stats of `bench.py --mode M --no-secondary`: ONE arithmetic per run, so
+#   OUTDIR/stats_{strict,fast}  rocprofv3 --kernel-trace --stats of `bench.py --mode M --no-secondary --steps 100`: ONE arithmetic per run, so
 #                               a kernel's average duration is that of the bench's own timed launches (the 3-D leg of the full
 #                               bench runs the same kernel template on slower data and would skew it)
 #   OUTDIR/stats_all            the same of the full default bench command (boids, 3-D legs, the issue-ceiling streams)
@@ -15,7 +15,7 @@ mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
 for mode in strict fast; do
     mkdir -p "$OUT/stats_$mode"
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$mode" -- python3 "$ROOT/bench.py" --mode $mode --no-secondary --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_${mode}_under_rocprof.log" 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$mode" -- python3 "$ROOT/bench.py" --mode $mode --no-secondary --steps 100 --warmup 3 --no-cpu-baseline > "$OUT/bench_${mode}_under_rocprof.log" 2>&1
     echo "stats $mode rc=$?"
 done
 mkdir -p "$OUT/stats_all"
