@@ -175,6 +175,14 @@ int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *po
 int nb_update_instance_boids(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
                              float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
                              float *old_velocities_xyz, size_t n_old_velocities, const nb_boids_params *params);
+/* update_instance_random (src/main.rs:381-402) as one call: the reference's three slices, the first
+ * min(n_instances, n_positions, n_velocities) bodies move (its zip, :386-389), the rest are not touched.  The reference draws
+ * from an unseeded thread_rng; here body n at call `step` draws from the counter-based stream (seed, step, n) of
+ * nb_step_random, so a run is reproducible and independent of how it is split: the distribution is the reference's, the
+ * draws are not. */
+int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                              float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step);
+
 /* Frees the context the two calls above keep (otherwise it is reclaimed with the process). */
 void nb_update_release(void);
 

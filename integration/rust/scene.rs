@@ -61,6 +61,10 @@ extern "C" {
         old_positions: *mut f32, n_old_positions: usize, velocities: *mut f32, n_velocities: usize,
         old_velocities: *mut f32, n_old_velocities: usize, params: *const NbBoidsParams,
     ) -> c_int;
+    fn nb_update_instance_random(
+        instances: *mut f32, n_instances: usize, positions: *mut f32, n_positions: usize,
+        velocities: *mut f32, n_velocities: usize, seed: u64, step: u64,
+    ) -> c_int;
 }
 
 impl Default for NbParams {
@@ -215,5 +219,27 @@ pub fn update_instance_boids(
     };
     if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
         panic!("update_instance_boids: {} ({})", msg, code);
+    }
+}
+
+/// The third controller (src/main.rs:381-385), its own three arguments.  `seed` and `step` index the library's
+/// counter-based stream (the reference draws from an unseeded `thread_rng`): pass the frame number as `step`.
+pub fn update_instance_random(
+    instances: &mut Vec<[[f32; 4]; 4]>,
+    positions: &mut Vec<Point3<f32>>,
+    velocities: &mut Vec<Vector3<f32>>,
+    seed: u64,
+    step: u64,
+) {
+    let rc = unsafe {
+        nb_update_instance_random(
+            instances.as_mut_ptr() as *mut f32, instances.len(),
+            positions.as_mut_ptr() as *mut f32, positions.len(),
+            velocities.as_mut_ptr() as *mut f32, velocities.len(),
+            seed, step,
+        )
+    };
+    if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
+        panic!("update_instance_random: {} ({})", msg, code);
     }
 }

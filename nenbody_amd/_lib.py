@@ -91,6 +91,7 @@ PROTOTYPES = {
     "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "nb_update_instance_nbody": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbParams)]),
     "nb_update_instance_boids": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbBoidsParams)]),
+    "nb_update_instance_random": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_uint64, c_uint64]),
     "nb_update_release": (None, []),
     "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
     "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),

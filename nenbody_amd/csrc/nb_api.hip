@@ -1169,8 +1169,9 @@ int update_fail(UpdateCache &uc, const char *who, int rc)
 // separate copy, launch and synchronisation shows.  (Replaying the five operations as a captured hipGraph was measured
 // too: 37 us per call at N = 100 against 30 us with plain launches, no difference at N = 2 048 -- not adopted.)
 // pos / vel: n bodies each; outputs: the first `count` bodies.
-int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const float *pos, const float *vel, size_t count,
-                     float *pos_out, float *vel_out, float *inst_out)
+// kind: 0 = n-body step, 1 = boids step, 2 = random-walk step (stream (seed, step, n) of nb_step_random)
+int update_roundtrip(nb_ctx *c, int kind, const nb_boids_params *bp, const float *pos, const float *vel, size_t count,
+                     float *pos_out, float *vel_out, float *inst_out, uint64_t seed = 0, uint64_t step = 0)
 {
     const size_t n = c->n, xyz = 3 * sizeof(float);
     int rc = ensure_xfer(c);
@@ -1186,7 +1187,8 @@ int update_roundtrip(nb_ctx *c, bool boids, const nb_boids_params *bp, const flo
     float *const in = zero_copy ? c->hxfer_dev : c->xfer, *const out = zero_copy ? c->hxfer_dev : c->xfer;
     if (!zero_copy) NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
     NB_HIP(c, nbk::launch_import(c->n, in, in + 3 * n, c->pos[0], c->vel, c->stream));
-    rc = boids ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
+    if (kind == 2) c->steps = step;  // the random walk's stream is indexed by the step counter
+    rc = kind == 2 ? nb_step_random(c, 1, seed) : kind == 1 ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
     if (rc != NB_OK) return rc;
     // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait per frame
     const bool with_status = c->status.dirty && c->status.w;
@@ -1263,7 +1265,7 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
     int rc;
     if (n <= kRoundtripMax) {
-        rc = update_roundtrip(uc.ctx, boids, bp, pos_src, vel_src, count, pos, vel, inst);
+        rc = update_roundtrip(uc.ctx, boids ? 1 : 0, bp, pos_src, vel_src, count, pos, vel, inst);
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
@@ -1304,6 +1306,48 @@ NB_EXPORT int nb_update_instance_boids(float *instances_16n, size_t n_instances,
     return update_common("nb_update_instance_boids", true, instances_16n, n_instances, positions_xyz, n_positions,
                          old_positions_xyz, n_old_positions, velocities_xyz, n_velocities, old_velocities_xyz, n_old_velocities,
                          nullptr, params);
+}
+
+// update_instance_random (src/main.rs:381-402): three slices, no snapshots; the zip (:386-389) bounds which bodies move.
+NB_EXPORT int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                        float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step)
+{
+    const char *who = "nb_update_instance_random";
+    if ((n_positions && !positions_xyz) || (n_velocities && !velocities_xyz) || (n_instances && !instances_16n)) {
+        g_tls_error = std::string(who) + ": null array with a nonzero length";
+        return NB_ERR_INVALID;
+    }
+    const size_t count = std::min(n_instances, std::min(n_positions, n_velocities));  // zip, main.rs:386-389
+    if (count == 0) return NB_OK;
+    if (count > 0xffffffffull) {
+        g_tls_error = std::string(who) + ": more than 2^32-1 bodies";
+        return NB_ERR_INVALID;
+    }
+    nb_params p;
+    nb_default_params(&p);
+    UpdateCache &uc = update_cache();
+    std::lock_guard<std::mutex> lock(uc.mu);
+    const uint32_t n = (uint32_t)count;  // every body walks on its own: the device set is exactly the bodies that move
+    if (!uc.ctx || uc.ctx->n != n || std::memcmp(&uc.p, &p, sizeof(p)) != 0) {
+        if (uc.ctx) nb_destroy(uc.ctx);
+        uc.ctx = nullptr;
+        int rc = nb_create(n, 1, &p, &uc.ctx);
+        if (rc != NB_OK) return update_fail(uc, who, rc);
+        uc.p = p;
+    }
+    int rc;
+    if (n <= kRoundtripMax) {
+        rc = update_roundtrip(uc.ctx, 2, nullptr, positions_xyz, velocities_xyz, count, positions_xyz, velocities_xyz, instances_16n, seed, step);
+    } else {
+        rc = nb_upload(uc.ctx, positions_xyz, velocities_xyz);
+        if (rc == NB_OK) {
+            uc.ctx->steps = step;
+            rc = nb_step_random(uc.ctx, 1, seed);
+        }
+        if (rc == NB_OK) rc = nb_download(uc.ctx, positions_xyz, velocities_xyz, instances_16n);
+    }
+    if (rc != NB_OK) return update_fail(uc, who, rc);
+    return NB_OK;
 }
 
 NB_EXPORT void nb_update_release(void)

@@ -92,6 +92,31 @@ def test_random_controller_matches_oracle_stream(nb, oracle):
     assert (bits(p2) == bits(pr2)).all() and (bits(v2) == bits(vr2)).all()
 
 
+@pytest.mark.parametrize("n", [300, 20000])          # both transfer paths of the drop-in calls (small / large sets)
+def test_update_instance_random_operator(nb, oracle, n):
+    """The reference's third controller as one call with its own three slices (main.rs:381-385): frame after frame it is the
+    oracle's stream (seed, step, n); its zip (main.rs:386-389) bounds which bodies move and the rest are left alone."""
+    pos, vel = oracle.init_state(n, 8)
+    p, v, inst = pos.copy(), vel.copy(), np.zeros((n, 4, 4), np.float32)
+    for step in range(3):
+        nb.update_instance_random(inst, p, v, seed=1234, step=step)
+    pr, vr, ir = oracle.random_run(pos, vel, 3, seed=1234, want_instances=True)
+    assert (bits(p) == bits(pr)).all() and (bits(v) == bits(vr)).all()
+    assert np.allclose(inst, ir, rtol=0, atol=1e-6)
+    # a shorter instance slice: only its bodies move; positions and velocities past it keep their bits
+    m = n // 3
+    p2, v2, inst2 = pos.copy(), vel.copy(), np.zeros((m, 4, 4), np.float32)
+    nb.update_instance_random(inst2, p2, v2, seed=7, step=5)
+    pr2, vr2 = oracle.random_run(pos[:m], vel[:m], 1, seed=7, first_step=5)
+    assert (bits(p2[:m]) == bits(pr2)).all() and (bits(v2[:m]) == bits(vr2)).all()
+    assert (bits(p2[m:]) == bits(pos[m:])).all() and (bits(v2[m:]) == bits(vel[m:])).all()
+    nb.update_instance_random(np.zeros((0, 4, 4), np.float32), p2, v2)      # an empty zip moves nothing
+    assert (bits(p2[m:]) == bits(pos[m:])).all()
+    with pytest.raises(TypeError):
+        nb.update_instance_random(inst2, p2.astype(np.float64), v2)
+    nb.update_release()
+
+
 def test_device_state_handoff(nb, oracle):
     """Zero-copy hand-off: the device pointers the context hands out hold the current records and model matrices."""
     import torch
