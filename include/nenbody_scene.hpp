@@ -187,4 +187,12 @@ inline void update_instance_boids(std::vector<Mat4> &instances, std::vector<Vec3
                                                    old_velocities.size(), params));
 }
 
+// update_instance_random (src/main.rs:381-385): the third controller, its own three arguments; `step` = the frame number
+inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &velocities,
+                                   uint64_t seed, uint64_t step)
+{
+    detail::update_status(nb_update_instance_random(detail::ptr(instances), instances.size(), detail::ptr(positions), positions.size(),
+                                                    detail::ptr(velocities), velocities.size(), seed, step));
+}
+
 }  // namespace nenbody

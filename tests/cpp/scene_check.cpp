@@ -48,6 +48,21 @@ int main(int argc, char **argv)
             } catch (const std::invalid_argument &) {
             }
         }
+        // the third controller (src/main.rs:381-385) as one call: the same stream twice gives the same bits, the zip bounds it
+        {
+            std::vector<nenbody::Vec3> rp = scene.positions, rv = scene.velocities, rp2 = rp, rv2 = rv;
+            std::vector<nenbody::Mat4> ri(n), ri2(n > 1 ? n / 2 : 1);
+            nenbody::update_instance_random(ri, rp, rv, 42, 7);
+            nenbody::update_instance_random(ri2, rp2, rv2, 42, 7);
+            const size_t m = ri2.size();
+            if (std::memcmp(rp.data(), rp2.data(), m * sizeof(nenbody::Vec3)) != 0 ||
+                std::memcmp(rv.data(), rv2.data(), m * sizeof(nenbody::Vec3)) != 0 ||
+                (m < n && std::memcmp(rp2.data() + m, scene.positions.data() + m, (n - m) * sizeof(nenbody::Vec3)) != 0) ||
+                std::memcmp(rp.data(), scene.positions.data(), n * sizeof(nenbody::Vec3)) == 0) {
+                std::fprintf(stderr, "update_instance_random: stream or zip wrong\n");
+                return 8;
+            }
+        }
         // the sharded host with a world of one (no exchange needed) must reproduce the same step
         {
             nenbody::Scene twin(n, prm, 1234);
