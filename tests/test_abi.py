@@ -334,3 +334,19 @@ def test_camera_constant_is_host_arithmetic_and_matches_the_oracle(oracle):
         with pytest.raises(ValueError):
             oracle.camera_constant(*bad)
     assert lib.nb_camera_constant(45.0, 1.0, 1.0, 10.0, None) == _lib.NB_ERR_INVALID
+
+
+def test_update_instance_random_validates_without_a_device():
+    """the argument checks of the third drop-in run before any device is touched: an empty zip is a no-op (main.rs:386-389
+    iterates nothing), a null array with a nonzero length is an error, and a real call without a GPU fails loudly"""
+    import nenbody_amd as nb
+    from nenbody_amd import _lib
+
+    lib = nb.load()
+    p = np.zeros((4, 3), np.float32)
+    assert lib.nb_update_instance_random(None, 0, p.ctypes.data, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_OK
+    assert lib.nb_update_instance_random(p.ctypes.data, 1, None, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_ERR_INVALID
+    assert "null array" in _lib.last_error()
+    if lib.nb_device_count() == 0:
+        inst = np.zeros((4, 4, 4), np.float32)
+        assert lib.nb_update_instance_random(inst.ctypes.data, 4, p.ctypes.data, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_ERR_NO_DEVICE
