@@ -9,6 +9,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# NB_RANDOM_CASES=N widens every family below to N seeded cases (a soak: `NB_RANDOM_CASES=1500 pytest tests/test_gpu_random_differential.py`)
+CASES = int(os.environ.get("NB_RANDOM_CASES", "36"))
+
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -30,7 +33,7 @@ def random_state(rng, n):
     return pos, vel
 
 
-@pytest.mark.parametrize("case", range(36))
+@pytest.mark.parametrize("case", range(CASES))
 def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(1000 + case)
     n = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 257, 700, 1500, 2300]))
@@ -61,7 +64,7 @@ def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     assert (bits(got_v)[~nanv] == bits(ref_v)[~nanv]).all(), what
 
 
-@pytest.mark.parametrize("case", range(36))
+@pytest.mark.parametrize("case", range(CASES))
 def test_boids_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(2000 + case)
     n = int(rng.choice([1, 3, 64, 100, 256, 300, 900, 1300, 2100]))
