@@ -304,6 +304,33 @@ def main():
         except Exception as e:  # pragma: no cover
             line["boids_controller"] = {"error": repr(e)}
 
+        if world == 1:
+            # the per-frame drop-in calls at the reference's own sizes (entity_count = 100, main.rs:654; its stated ceiling
+            # 2 048, main.rs:653): upload + one step + download of positions, velocities and model matrices, per call
+            leg["name"] = "dropin_call_at_reference_sizes"
+            try:
+                import numpy as np
+
+                lat = {}
+                for m in (100, 2048):
+                    p0, v0 = nb.init_state(m, 1234)
+                    inst = np.zeros((m, 4, 4), np.float32)
+                    row = {}
+                    for name, fn in (("update_instance_nbody", nb.update_instance_nbody), ("update_instance_boids", nb.update_instance_boids)):
+                        p, v = p0.copy(), v0.copy()
+                        op, ov = np.zeros_like(p), np.zeros_like(v)
+                        for _ in range(20):
+                            fn(inst, p, op, v, ov)
+                        t0 = time.perf_counter()
+                        for _ in range(200):
+                            fn(inst, p, op, v, ov)
+                        row[name] = round((time.perf_counter() - t0) / 200 * 1e6, 1)
+                    lat[str(m)] = row
+                nb.update_release()
+                line["dropin_call_us"] = {"unit": "microseconds per call (PCIe-inclusive; never `value`)", "entities": lat}
+            except Exception as e:  # pragma: no cover
+                line["dropin_call_us"] = {"error": repr(e)}
+
     if world == 1:
         # Last of the GPU legs: these streams load the vector ALU harder than any kernel here, and the part answers a
         # sustained load by lowering its clock for tens of milliseconds -- timed before the other legs they slow them down.
