@@ -339,7 +339,7 @@ def main():
             import ctypes
 
             rates = {}
-            for name, mix in (("fma", 0), ("mix", 1)):
+            for name, mix in (("fma", 0), ("mix", 1), ("pk_mix", 2)):
                 r = ctypes.c_double()
                 nb._lib.check(nb.load().nb_selftest_valu_rate(mix, 0.05, ctypes.byref(r)))
                 rates[name] = r.value
@@ -349,10 +349,12 @@ def main():
             line["roofline"]["measured_issue_ceiling"] = {
                 "fma_stream_tflops": 2.0 * rates["fma"] / 1e12, "fma_stream_frac_of_spec_peak": 2.0 * rates["fma"] / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                 "mix_stream_lane_ops_per_s": rates["mix"], "fma_stream_lane_ops_per_s": rates["fma"],
+                "pk_mix_stream_lane_ops_per_s": rates["pk_mix"],
                 "kernel_issue_slots_per_s": kernel_rate, "kernel_over_mix_stream": kernel_rate / rates["mix"],
+                "kernel_over_pk_mix_stream": kernel_rate / rates["pk_mix"],
                 "what": "register-only streams of independent vector instructions on every SIMD (8 waves each), 50 ms each, in this "
                         "process after the timed legs: v_fma_f32 only (what the spec peak assumes; the part clocks down under it) and "
-                        "the folds' own mix of fma/add/mul/sub.  kernel_issue_slots_per_s = interactions/s x the issue slots the "
+                        "the folds' own mix of fma/add/mul/sub, as plain and as packed (v_pk_*, two lane operations each) instructions.  kernel_issue_slots_per_s = interactions/s x the issue slots the "
                         "kernel executes per interaction (full-rate ops + 4 per v_rcp_f32): kernel_over_mix_stream says how close "
                         "the kernel runs to what this device issues for that kind of instruction"}
         except Exception as e:  # pragma: no cover

@@ -207,8 +207,9 @@ int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
 /* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
  * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
  * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in
- * the proportion of the pair folds (same issue slots, less power: the part clocks it higher).  bench.py prints both beside
- * the spec peak its roofline fraction is quoted against. */
+ * the proportion of the pair folds (same issue slots, less power: the part clocks it higher); mix 2: that mix as v_pk_*
+ * instructions, two lane-operations each (what the folds mostly issue).  bench.py prints them beside the spec peak its
+ * roofline fraction is quoted against. */
 int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
 
 /* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,

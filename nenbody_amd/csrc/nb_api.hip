@@ -1484,8 +1484,8 @@ NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
 
 NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s)
 {
-    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix != 0 && mix != 1)) {
-        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0 or 1 and 0 < seconds <= 2";
+    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix < 0 || mix > 2)) {
+        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0, 1 or 2 and 0 < seconds <= 2";
         return NB_ERR_INVALID;
     }
     int rc = check_device(&g_tls_error);
@@ -1522,7 +1522,8 @@ NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_pe
         g_tls_error = std::string("nb_selftest_valu_rate: ") + hipGetErrorString(e);
         return NB_ERR_HIP;
     }
-    *lane_ops_per_s = 64.0 * (double)trips * 256.0 * (double)blocks / ((double)ms * 1e-3);
+    // 64 instructions per trip and lane; a packed instruction (mix 2) is two lane operations
+    *lane_ops_per_s = (mix == 2 ? 128.0 : 64.0) * (double)trips * 256.0 * (double)blocks / ((double)ms * 1e-3);
     return NB_OK;
 }
 

@@ -270,7 +270,7 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     assert lib.nb_selftest_valu_rate(0, 0.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_valu_rate(0, 0.05, None) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_valu_rate(1, 5.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_valu_rate(2, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(3, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
     bad = ctypes.c_uint64()
     assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_rcp_scaling(5, 4, ctypes.byref(bad)) == _lib.NB_ERR_INVALID

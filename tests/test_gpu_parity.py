@@ -1169,3 +1169,17 @@ def test_roctx_ranges_do_not_change_results(nb, oracle, monkeypatch):
     with nb.NativeShard(pos, vel) as sh:
         sh.step(2)
         assert_bits_equal(sh.positions(), oracle.run(pos, vel, 2)[0])
+
+
+def test_valu_rate_streams_are_sane(nb):
+    """nb_selftest_valu_rate: the three yardsticks bench.py prints (pure fma, the folds' mix as plain instructions, the same mix
+    as packed instructions) are positive, below the spec lane rate, and ordered as measured: fma < mix <= packed mix."""
+    lib = nb.load()
+    rates = []
+    for mix in (0, 1, 2):
+        r = ctypes.c_double()
+        assert lib.nb_selftest_valu_rate(mix, 0.02, ctypes.byref(r)) == 0
+        rates.append(r.value)
+    spec = 256 * 128 * 2.4e9          # lanes x clock: 7.9e13 lane-operations/s
+    assert all(1e13 < x < 1.05 * spec for x in rates), rates
+    assert rates[0] < rates[1] <= 1.2 * rates[2] and rates[2] > 0.9 * rates[1], rates
