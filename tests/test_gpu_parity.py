@@ -1183,3 +1183,49 @@ def test_valu_rate_streams_are_sane(nb):
     spec = 256 * 128 * 2.4e9          # lanes x clock: 7.9e13 lane-operations/s
     assert all(1e13 < x < 1.05 * spec for x in rates), rates
     assert rates[0] < rates[1] <= 1.2 * rates[2] and rates[2] > 0.9 * rates[1], rates
+
+
+def test_contexts_on_concurrent_host_threads(nb, oracle):
+    """A context is single-owner (`Scene: Send`, not `Sync`), but DIFFERENT contexts may be driven from
+    different host threads at the same time -- each has its own stream, plans are cached per thread, the last error is
+    thread-local -- and the launch API may be called from several threads too.  Four threads, four sets of different sizes and
+    arithmetic (block chain, j-parallel, FAST, boids), stepping concurrently: every result is the oracle's."""
+    import threading
+
+    cases = [(4096, "strict"), (700, "strict"), (3000, "boids"), (2500, "fast"), (5000, "strict"), (1800, "boids")]
+    results, errors = {}, []
+
+    def work(idx, n, kind):
+        try:
+            pos, vel = oracle.init_state(n, seed=900 + idx)
+            for _ in range(3):                     # several contexts per thread, one after another
+                if kind == "boids":
+                    with nb.Scene(pos, vel) as sc:
+                        sc.step_boids_n(3)
+                        results[idx] = sc.state()
+                else:
+                    mode = nb.NB_MODE_FAST if kind == "fast" else nb.NB_MODE_STRICT
+                    with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
+                        sc.step_n(3)
+                        results[idx] = sc.state()
+        except Exception as e:  # pragma: no cover
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i, n, k)) for i, (n, k) in enumerate(cases)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (n, kind) in enumerate(cases):
+        pos, vel = oracle.init_state(n, seed=900 + i)
+        p, v = results[i]
+        if kind == "boids":
+            p_ref, v_ref = oracle.boids_run(pos, vel, 3)
+        else:
+            p_ref, v_ref = oracle.run(pos, vel, 3)
+        if kind == "fast":
+            assert np.abs(p - p_ref).max() < 1e-4, (i, n)
+        else:
+            assert_bits_equal(p, p_ref, f"thread {i}: {kind} n={n}")
+            assert_bits_equal(v, v_ref, f"thread {i}: {kind} n={n}")
