@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- body-updates/s of nenbody's all-pairs gravity + Euler step on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                 (ranks started by the caller: RANK / WORLD_SIZE in the env)
 
 Workload (BASELINE.json): N = 131 072 bodies, reference initial distributions (src/main.rs:738-747, seeded),
 reference constants (src/main.rs:411-413); a "step" is one update_instance_nbody over the whole set.  With N
@@ -64,12 +64,8 @@ def committed_traffic(nb, kernels, n, count):
 
 
 def step_kernels(nb, mode, n, count):
-    """the kernels one step launches, dominant one first (nb_api.hip:make_plan)"""
-    if mode == nb.NB_MODE_FAST:  # 8-wave workgroups x grid.y slices; the slices' partial sums are combined by a second kernel
-        return ["step_fast_wave_kernel", "integrate_partials_kernel"]
-    if count > 65536:
-        return ["step_strict_kernel"]
-    return ["step_strict_bc_kernel", "planes_kernel"] if n >= 4096 else ["step_strict_pc_kernel"]
+    """the kernels one step launches, dominant one first -- asked of the library (nb_diag_plan), not restated here"""
+    return nb._lib.planned_kernels(nb.default_params(mode=mode), n, count)
 
 
 def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False):
@@ -137,6 +133,20 @@ def main():
                     help="seconds the informational legs (other mode, 3-D data, boids, CPU baseline) may take before the headline "
                          "is printed without them and the run exits 3")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started bare with --gpus N: run the N ranks as CHILD processes of a parent that never touches the GPU (no torch
+        # import, no HIP call here; nothing is exec'd over an initialised process), relay their output -- rank 0 prints the
+        # JSON line -- and leave with their exit code.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch
     import torch.distributed as dist

@@ -8,7 +8,8 @@
  * meant to hold.
  * The reference has no FFI of its own; each entry point below cites the reference
  * interface it stands in for.  INTEGRATION.md shows the Rust `extern "C"` block and the
- * `Scene` shim a maintainer would add.
+ * `Scene` shim a maintainer would add.  Only what a host binds is declared here; the library's self-tests and the test
+ * suite's switches are in nenbody_diag.h.
  *
  * Conventions
  *  - plain pointers and sizes only; no C++/torch types.
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
 
 typedef enum nb_status {
     NB_OK = 0,
@@ -166,8 +167,9 @@ uint64_t nb_steps_done(const nb_ctx *ctx);
  *   - boids folds rule 1 and rule 2 over old_positions.iter() (main.rs:471, 482) and rule 3 over old_velocities.iter()
  *     (main.rs:494): each fold has its own slice's length, nothing is indexed by the other's, so positions and
  *     velocities of different lengths are served as the reference serves them (the zip bounds which bodies move).
- * One upload, one step, one download per call.  The device context lives inside the library between calls and is
- * rebuilt when the body count or the constants change; calls are serialised by an internal lock.
+ * One upload, one step, one download per call.  The device contexts live inside the library between calls: up to three,
+ * keyed by controller, body count and constants (a host may alternate controllers or entity counts from frame to frame; only
+ * a fourth shape rebuilds one); calls are serialised by an internal lock.
  * params == NULL -> the reference constants. */
 int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
                              float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
@@ -175,50 +177,21 @@ int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *po
 int nb_update_instance_boids(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
                              float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
                              float *old_velocities_xyz, size_t n_old_velocities, const nb_boids_params *params);
-/* update_instance_random (src/main.rs:381-402) as one call: the reference's three slices, the first
- * min(n_instances, n_positions, n_velocities) bodies move (its zip, :386-389), the rest are not touched.  The reference draws
- * from an unseeded thread_rng; here body n at call `step` draws from the counter-based stream (seed, step, n) of
- * nb_step_random, so a run is reproducible and independent of how it is split: the distribution is the reference's, the
- * draws are not. */
+/* update_instance_random(instances, positions, velocities) (src/main.rs:381-385) as one call: the reference's three slices,
+ * the first min(n_instances, n_positions, n_velocities) bodies move (its zip, :386-389), the rest are not touched.  The
+ * reference draws from an unseeded thread_rng; here body n at the library's k-th call draws from the counter-based stream
+ * (seed, k, n) of nb_step_random, with the seed and the call counter kept inside the library (nb_update_random_seed sets the
+ * seed and restarts the counter; the default seed is fixed, so a run is reproducible): the distribution is the reference's,
+ * the draws are not.  nb_update_instance_random_seeded is the same step with the stream position given by the caller
+ * (independent of how a run is split across calls or hosts). */
 int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                              float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step);
+                              float *velocities_xyz, size_t n_velocities);
+int nb_update_instance_random_seeded(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                     float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step);
+void nb_update_random_seed(uint64_t seed);
 
-/* Frees the context the two calls above keep (otherwise it is reclaimed with the process). */
+/* Frees the contexts the calls above keep (otherwise they are reclaimed with the process). */
 void nb_update_release(void);
-
-/* Diagnostic: checks on the GPU that STRICT's shared-reciprocal division ladder equals the IEEE binary32 divide on
- * `pairs` random (numerator, denominator) pairs drawn over the whole exponent rectangle the range guard admits for
- * `params` (NULL = defaults), structured mantissas included.  *mismatches receives the number of differing results
- * (expected 0); bad_pair, if non-NULL, receives one offending (n, d).  Returns NB_ERR_UNSUPPORTED when the parameters
- * leave no guarded range (STRICT then always uses the IEEE divide). */
-int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair);
-
-/* Diagnostic, and the proof STRICT's division rests on.  With every intermediate normal (what the range guard ensures)
- * the ladder commutes with scaling numerator and denominator by powers of two, so its result depends on the two 24-bit
- * significands only.  nb_selftest_ladder compares it with the IEEE divide for `count` denominator significands starting
- * at `first_significand` (both in [0, 2^23); d = 1.significand) against ALL 2^23 numerator significands, on the GPU;
- * (0, 2^23) is the whole space, 7.0e13 pairs, under a minute on one MI355X.  *mismatches receives the number of differing
- * quotients (expected 0); bad_pair, if non-NULL, one offending (n, d).  nb_selftest_rcp_scaling checks the one step that
- * is not IEEE arithmetic: v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for every significand m and k in [k_lo, k_hi]
- * (-125 <= k_lo <= k_hi <= 125); *violations receives the count (expected 0). */
-int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
-int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
-
-/* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
- * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
- * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in
- * the proportion of the pair folds (same issue slots, less power: the part clocks it higher); mix 2: that mix as v_pk_*
- * instructions, two lane-operations each (what the folds mostly issue).  bench.py prints them beside the spec peak its
- * roofline fraction is quoted against. */
-int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
-
-/* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
- * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
- * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_SHARD_RCCL_SOLO, NB_DROPIN_ZERO_COPY, and NB_ROCTX = 1: roctx ranges
- * around the step loops and the exchange, for rocprofv3 --marker-trace) are read ONCE per process, at first use; no launch
- * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
- * and shards keep the launch shape chosen when they were created. */
-int nb_debug_reload_env(void);
 
 /* -- launch API: caller-owned device memory ------------------------------------------------------------ *
  * For hosts that own the device buffers and the exchange step themselves (one process per GPU, RCCL

@@ -1,0 +1,61 @@
+/*
+ * nenbody_diag.h -- diagnostic entry points of libnenbody_hip.so: self-tests, measurement helpers and the switches the
+ * parity tests and tools/ use to pin a kernel form.  NOT part of the drop-in boundary (include/nenbody.h): a host that
+ * replaces the reference's update functions binds nothing from this file.
+ */
+#ifndef NENBODY_DIAG_H
+#define NENBODY_DIAG_H
+
+#include "nenbody.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic: checks on the GPU that STRICT's shared-reciprocal division ladder equals the IEEE binary32 divide on
+ * `pairs` random (numerator, denominator) pairs drawn over the whole exponent rectangle the range guard admits for
+ * `params` (NULL = defaults), structured mantissas included.  *mismatches receives the number of differing results
+ * (expected 0); bad_pair, if non-NULL, receives one offending (n, d).  Returns NB_ERR_UNSUPPORTED when the parameters
+ * leave no guarded range (STRICT then always uses the IEEE divide). */
+int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair);
+
+/* Diagnostic, and the proof STRICT's division rests on.  With every intermediate normal (what the range guard ensures)
+ * the ladder commutes with scaling numerator and denominator by powers of two, so its result depends on the two 24-bit
+ * significands only.  nb_selftest_ladder compares it with the IEEE divide for `count` denominator significands starting
+ * at `first_significand` (both in [0, 2^23); d = 1.significand) against ALL 2^23 numerator significands, on the GPU;
+ * (0, 2^23) is the whole space, 7.0e13 pairs, under a minute on one MI355X.  *mismatches receives the number of differing
+ * quotients (expected 0); bad_pair, if non-NULL, one offending (n, d).  nb_selftest_rcp_scaling checks the one step that
+ * is not IEEE arithmetic: v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for every significand m and k in [k_lo, k_hi]
+ * (-125 <= k_lo <= k_hi <= 125); *violations receives the count (expected 0). */
+int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
+int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
+
+/* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
+ * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
+ * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in
+ * the proportion of the pair folds (same issue slots, less power: the part clocks it higher); mix 2: that mix as v_pk_*
+ * instructions, two lane-operations each (what the folds mostly issue).  bench.py prints them beside the spec peak its
+ * roofline fraction is quoted against. */
+int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
+
+/* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
+ * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
+ * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_DROPIN_ZERO_COPY, and NB_ROCTX = 1: roctx ranges
+ * around the step loops and the exchange, for rocprofv3 --marker-trace) are read ONCE per process, at first use; no launch
+ * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
+ * and shards keep the launch shape chosen when they were created. */
+int nb_debug_reload_env(void);
+
+/* Test-only: with on != 0, nb_shard_use_rccl builds a communicator of ONE rank whatever the shard's world is, and the
+ * all-gather then moves nothing -- the whole RCCL call path of a step on a one-GPU box (tests, tools/step_overhead.py).  A
+ * process switch, deliberately not an environment variable: nothing a deployment inherits can arm it. */
+int nb_diag_rccl_solo(int on);
+
+/* The kernels one step of this shape launches, dominant one first, comma separated ("step_strict_bc_kernel,planes_kernel"),
+ * as the library itself plans the launch (make_plan): what bench.py labels its roofline with. */
+int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t count, char *out, size_t out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NENBODY_DIAG_H */

@@ -187,12 +187,20 @@ inline void update_instance_boids(std::vector<Mat4> &instances, std::vector<Vec3
                                                    old_velocities.size(), params));
 }
 
-// update_instance_random (src/main.rs:381-385): the third controller, its own three arguments; `step` = the frame number
+// update_instance_random(instances, positions, velocities) (src/main.rs:381-385): the third controller, its own three
+// arguments; the library keeps the seed and counts the calls (nb_update_random_seed restarts the stream)
+inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &velocities)
+{
+    detail::update_status(nb_update_instance_random(detail::ptr(instances), instances.size(), detail::ptr(positions), positions.size(),
+                                                    detail::ptr(velocities), velocities.size()));
+}
+
+// the same step at a stream position the caller names: `step` = the frame number
 inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &velocities,
                                    uint64_t seed, uint64_t step)
 {
-    detail::update_status(nb_update_instance_random(detail::ptr(instances), instances.size(), detail::ptr(positions), positions.size(),
-                                                    detail::ptr(velocities), velocities.size(), seed, step));
+    detail::update_status(nb_update_instance_random_seeded(detail::ptr(instances), instances.size(), detail::ptr(positions),
+                                                           positions.size(), detail::ptr(velocities), velocities.size(), seed, step));
 }
 
 }  // namespace nenbody

@@ -63,8 +63,13 @@ extern "C" {
     ) -> c_int;
     fn nb_update_instance_random(
         instances: *mut f32, n_instances: usize, positions: *mut f32, n_positions: usize,
+        velocities: *mut f32, n_velocities: usize,
+    ) -> c_int;
+    fn nb_update_instance_random_seeded(
+        instances: *mut f32, n_instances: usize, positions: *mut f32, n_positions: usize,
         velocities: *mut f32, n_velocities: usize, seed: u64, step: u64,
     ) -> c_int;
+    fn nb_update_random_seed(seed: u64);
 }
 
 impl Default for NbParams {
@@ -222,9 +227,28 @@ pub fn update_instance_boids(
     }
 }
 
-/// The third controller (src/main.rs:381-385), its own three arguments.  `seed` and `step` index the library's
-/// counter-based stream (the reference draws from an unseeded `thread_rng`): pass the frame number as `step`.
+/// The third controller with the reference's own signature (src/main.rs:381-385): a drop-in for the function body.
+/// The reference draws from an unseeded `thread_rng`; the library draws from a counter-based stream whose seed and call
+/// counter it keeps itself (`update_random_seed` restarts it).
 pub fn update_instance_random(
+    instances: &mut Vec<[[f32; 4]; 4]>,
+    positions: &mut Vec<Point3<f32>>,
+    velocities: &mut Vec<Vector3<f32>>,
+) {
+    let rc = unsafe {
+        nb_update_instance_random(
+            instances.as_mut_ptr() as *mut f32, instances.len(),
+            positions.as_mut_ptr() as *mut f32, positions.len(),
+            velocities.as_mut_ptr() as *mut f32, velocities.len(),
+        )
+    };
+    if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
+        panic!("update_instance_random: {} ({})", msg, code);
+    }
+}
+
+/// The same step at a stream position the caller names (`step` = the frame number): independent of how a run is split.
+pub fn update_instance_random_seeded(
     instances: &mut Vec<[[f32; 4]; 4]>,
     positions: &mut Vec<Point3<f32>>,
     velocities: &mut Vec<Vector3<f32>>,
@@ -232,7 +256,7 @@ pub fn update_instance_random(
     step: u64,
 ) {
     let rc = unsafe {
-        nb_update_instance_random(
+        nb_update_instance_random_seeded(
             instances.as_mut_ptr() as *mut f32, instances.len(),
             positions.as_mut_ptr() as *mut f32, positions.len(),
             velocities.as_mut_ptr() as *mut f32, velocities.len(),
@@ -240,6 +264,11 @@ pub fn update_instance_random(
         )
     };
     if let Err(SceneError(code, msg)) = check(rc, std::ptr::null()) {
-        panic!("update_instance_random: {} ({})", msg, code);
+        panic!("update_instance_random_seeded: {} ({})", msg, code);
     }
+}
+
+/// Seed of `update_instance_random`'s stream; restarts its call counter.
+pub fn update_random_seed(seed: u64) {
+    unsafe { nb_update_random_seed(seed) }
 }

@@ -7,7 +7,7 @@ One path only: ``update_instance_nbody`` (reference src/main.rs:404-441), behind
 from ._lib import (NB_MODE_FAST, NB_MODE_STRICT, NbBoidsParams, NbError, NbParams, default_boids_params,  # noqa: F401
                    default_params, load)
 from .scene import (Scene, camera_constant, init_state, update_instance_boids, update_instance_nbody,  # noqa: F401
-                    update_instance_random, update_release)
+                    update_instance_random, update_instance_random_seeded, update_random_seed, update_release)
 from .dist import NativeShard, ShardedScene, comm_id, partition  # noqa: F401
 
 
@@ -18,6 +18,6 @@ def reload_env() -> None:
     load().nb_debug_reload_env()
 
 
-__all__ = ["reload_env", "Scene", "ShardedScene", "NativeShard", "comm_id", "partition", "init_state", "camera_constant", "update_instance_nbody", "update_instance_boids", "update_instance_random", "update_release",
+__all__ = ["reload_env", "Scene", "ShardedScene", "NativeShard", "comm_id", "partition", "init_state", "camera_constant", "update_instance_nbody", "update_instance_boids", "update_instance_random", "update_instance_random_seeded", "update_random_seed", "update_release",
            "default_params", "default_boids_params", "load", "NbParams", "NbBoidsParams", "NbError", "NB_MODE_STRICT",
            "NB_MODE_FAST"]

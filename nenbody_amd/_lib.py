@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NENBODY_LIB overrides the path (kernel experiments: a second build of the same sources with other flags)
 LIB_PATH = os.environ.get("NENBODY_LIB") or os.path.join(_HERE, "lib", "libnenbody_hip.so")
 
-NB_ABI_VERSION = 1
+NB_ABI_VERSION = 2
 NB_OK = 0
 NB_ERR_INVALID = -1
 NB_ERR_NO_DEVICE = -2
@@ -91,12 +91,10 @@ PROTOTYPES = {
     "nb_launch_random_step": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "nb_update_instance_nbody": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbParams)]),
     "nb_update_instance_boids": (c_int, [c_void_p, c_size_t] * 5 + [POINTER(NbBoidsParams)]),
-    "nb_update_instance_random": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_uint64, c_uint64]),
+    "nb_update_instance_random": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]),
+    "nb_update_instance_random_seeded": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_uint64, c_uint64]),
+    "nb_update_random_seed": (None, [c_uint64]),
     "nb_update_release": (None, []),
-    "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
-    "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
-    "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
-    "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double)]),
     "nb_sync": (c_int, [c_void_p]),
     "nb_steps_done": (c_uint64, [c_void_p]),
     "nb_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32]),
@@ -111,7 +109,6 @@ PROTOTYPES = {
          c_void_p],
     ),
     "nb_launch_status": (c_int, [c_void_p]),
-    "nb_debug_reload_env": (c_int, []),
     "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
     "nb_launch_unpack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
@@ -128,6 +125,17 @@ PROTOTYPES = {
     "nb_shard_download": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_shard_sync": (c_int, [c_void_p]),
     "nb_shard_last_error": (c_char_p, [c_void_p]),
+}
+
+# every symbol include/nenbody_diag.h declares (self-tests, the test suite's switches): not part of the drop-in boundary
+DIAG_PROTOTYPES = {
+    "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
+    "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
+    "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
+    "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double)]),
+    "nb_debug_reload_env": (c_int, []),
+    "nb_diag_rccl_solo": (c_int, [c_int]),
+    "nb_diag_plan": (c_int, [POINTER(NbParams), c_uint32, c_uint32, ctypes.c_char_p, c_size_t]),
 }
 
 _lib = None
@@ -172,7 +180,7 @@ def load() -> ctypes.CDLL:
         )
     _preload_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (restype, argtypes) in PROTOTYPES.items():
+    for name, (restype, argtypes) in list(PROTOTYPES.items()) + list(DIAG_PROTOTYPES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
@@ -197,6 +205,13 @@ def kernel_source_sha() -> str:
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
+
+
+def planned_kernels(params: "NbParams", n_total: int, count: int) -> list:
+    """The kernels one step of this shape launches, dominant one first, as the library plans it (nb_diag_plan)."""
+    buf = ctypes.create_string_buffer(256)
+    check(load().nb_diag_plan(ctypes.byref(params), n_total, count, buf, len(buf)))
+    return buf.value.decode().split(",")
 
 
 def default_params(mode: int = NB_MODE_STRICT, tile: int = 0) -> NbParams:

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/nenbody.h"
+#include "../../include/nenbody_diag.h"
 #include "nb_kernels.h"
 
 #define NB_EXPORT extern "C" __attribute__((visibility("default")))
@@ -43,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, shard_rccl_solo, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -59,6 +60,9 @@ Knob read_knob(const char *name)
 }
 
 std::atomic<const DebugOverrides *> g_overrides{nullptr};
+// nb_diag_rccl_solo (include/nenbody_diag.h): the test suite's way to run the RCCL leg of a shard on a one-GPU box.  Not an
+// environment variable: nothing a deployment inherits can turn a world of 8 into eight communicators of one.
+std::atomic<bool> g_rccl_solo{false};
 std::mutex g_overrides_mu;
 
 const DebugOverrides *parse_overrides(uint32_t generation)
@@ -85,7 +89,6 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_force = read_knob("NB_BOIDS_FORCE");
     d->dropin_zero_copy = read_knob("NB_DROPIN_ZERO_COPY");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
-    d->shard_rccl_solo = read_knob("NB_SHARD_RCCL_SOLO");
     d->roctx = read_knob("NB_ROCTX");
     d->generation = generation;
     return d;
@@ -160,7 +163,7 @@ void fast_split(uint32_t n_fold, uint32_t count, uint32_t ib, uint32_t waves, ui
 {
     const DebugOverrides &dbg = overrides();
     if (waves && *tile == 1024u) *tile = 512u;  // the wave form stages a whole tile per wave: 256 or 512 records
-    if (waves && *tile == 512u && ib == 1) *tile = 256u;
+    if (waves && *tile == 512u && (ib == 1 || waves == 1)) *tile = 256u;  // built 512-record shapes: 4, 8, 16 waves at 2 / 4 bodies per lane
     const uint32_t bodies = waves ? 64u * ib : 256u * ib, chunk_waves = waves ? 1u : 4u;
     const uint32_t blocks = (count + bodies - 1u) / bodies;
     const uint32_t max_by_tiles = std::max(1u, (n_fold + *tile - 1u) / *tile);
@@ -521,8 +524,8 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
 
 int check_device(std::string *err)
 {
-    static bool seen = false;  // a device does not disappear; cache only the positive answer
-    if (seen) return NB_OK;
+    static std::atomic<bool> seen{false};  // a device does not disappear; cache only the positive answer (any thread may ask)
+    if (seen.load(std::memory_order_relaxed)) return NB_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -531,7 +534,7 @@ int check_device(std::string *err)
                "); this library has no CPU path";
         return NB_ERR_NO_DEVICE;
     }
-    seen = true;
+    seen.store(true, std::memory_order_relaxed);
     return NB_OK;
 }
 
@@ -1142,11 +1145,24 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
 
 // ---- one-call drop-ins (src/main.rs:404-410, 443-449) ---------------------------------------------------
 namespace {
+// The drop-in calls keep their device contexts between frames.  A host may alternate controllers or entity counts from
+// frame to frame (the reference swaps controllers by editing main.rs:925), so a few contexts are kept, keyed by controller,
+// body count and constants; the least recently used slot is rebuilt (stream + five allocations) only when a FOURTH shape shows up.
+struct UpdateSlot {
+    nb_ctx *ctx = nullptr;
+    int kind = -1;  // 0 = n-body, 1 = boids, 2 = random walk
+    nb_params p{};
+    uint64_t used = 0;
+};
 struct UpdateCache {
     std::mutex mu;
-    nb_ctx *ctx = nullptr;
-    nb_params p{};
+    static constexpr int kSlots = 3;
+    UpdateSlot slot[kSlots];
+    uint64_t clock = 0;
+    nb_ctx *last = nullptr;  // whose error message update_fail reports
     std::vector<float> pos_full, vel_full, tmp;
+    // update_instance_random (three slices, main.rs:381-385): the library's own stream position
+    uint64_t random_seed = 0x6e656e626f6479ull, random_calls = 0;
 };
 // never destroyed: a static destructor could run after the HIP runtime's own teardown
 UpdateCache &update_cache()
@@ -1157,8 +1173,32 @@ UpdateCache &update_cache()
 
 int update_fail(UpdateCache &uc, const char *who, int rc)
 {
-    g_tls_error = std::string(who) + ": " + (uc.ctx ? uc.ctx->err : g_tls_error);
+    g_tls_error = std::string(who) + ": " + (uc.last ? uc.last->err : g_tls_error);
     return rc;
+}
+
+// the context for (kind, n, p): a kept one, or a new one in the least recently used slot.  uc.mu is held.
+int update_context(UpdateCache &uc, int kind, uint32_t n, const nb_params &p, nb_ctx **out)
+{
+    UpdateSlot *victim = &uc.slot[0];
+    for (UpdateSlot &sl : uc.slot) {
+        if (sl.ctx && sl.kind == kind && sl.ctx->n == n && std::memcmp(&sl.p, &p, sizeof(p)) == 0) {
+            sl.used = ++uc.clock;
+            uc.last = *out = sl.ctx;
+            return NB_OK;
+        }
+        if (!sl.ctx ? victim->ctx != nullptr : (victim->ctx && sl.used < victim->used)) victim = &sl;
+    }
+    if (victim->ctx) nb_destroy(victim->ctx);
+    victim->ctx = nullptr;
+    uc.last = nullptr;
+    int rc = nb_create(n, 1, &p, &victim->ctx);
+    if (rc != NB_OK) return rc;
+    victim->kind = kind;
+    victim->p = p;
+    victim->used = ++uc.clock;
+    uc.last = *out = victim->ctx;
+    return NB_OK;
 }
 
 // upload + one step + download with ONE host<->device copy each way and one wait: the per-frame cost of the drop-in
@@ -1241,13 +1281,9 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     UpdateCache &uc = update_cache();
     std::lock_guard<std::mutex> lock(uc.mu);
     const uint32_t n = (uint32_t)n_set;
-    if (!uc.ctx || uc.ctx->n != n || std::memcmp(&uc.p, &p, sizeof(p)) != 0) {
-        if (uc.ctx) nb_destroy(uc.ctx);
-        uc.ctx = nullptr;
-        int rc = nb_create(n, 1, &p, &uc.ctx);
-        if (rc != NB_OK) return update_fail(uc, who, rc);
-        uc.p = p;
-    }
+    nb_ctx *ctx = nullptr;
+    int rc = update_context(uc, boids ? 1 : 0, n, p, &ctx);
+    if (rc != NB_OK) return update_fail(uc, who, rc);
     const float *pos_src = opos, *vel_src = ovel;
     if (n_pos < n_set) {  // boids only
         uc.pos_full.assign(n_set * 3, std::nanf(""));
@@ -1263,23 +1299,22 @@ int update_common(const char *who, bool boids, float *inst, size_t n_inst, float
     // Small sets are all latency: one copy each way through pinned memory (41 us per call at N = 100, 87 us at 2 048,
     // against 104 / 143 us with separate copies).  Large sets are all bandwidth: copy straight from and to the caller's
     // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
-    int rc;
     if (n <= kRoundtripMax) {
-        rc = update_roundtrip(uc.ctx, boids ? 1 : 0, bp, pos_src, vel_src, count, pos, vel, inst);
+        rc = update_roundtrip(ctx, boids ? 1 : 0, bp, pos_src, vel_src, count, pos, vel, inst);
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
-    rc = nb_upload(uc.ctx, pos_src, vel_src);
-    if (rc == NB_OK) rc = boids ? nb_step_boids(uc.ctx, 1, bp) : nb_step(uc.ctx, 1);
+    rc = nb_upload(ctx, pos_src, vel_src);
+    if (rc == NB_OK) rc = boids ? nb_step_boids(ctx, 1, bp) : nb_step(ctx, 1);
     if (rc != NB_OK) return update_fail(uc, who, rc);
     if (count == n_set) {  // the usual case: all three slices as long as the set
-        rc = nb_download(uc.ctx, pos, vel, inst);
+        rc = nb_download(ctx, pos, vel, inst);
         if (rc != NB_OK) return update_fail(uc, who, rc);
         return NB_OK;
     }
     uc.tmp.resize(n_set * 22);
     float *pos_tmp = uc.tmp.data(), *vel_tmp = pos_tmp + 3 * n_set, *inst_tmp = pos_tmp + 6 * n_set;
-    rc = nb_download(uc.ctx, pos_tmp, vel_tmp, inst_tmp);
+    rc = nb_download(ctx, pos_tmp, vel_tmp, inst_tmp);
     if (rc != NB_OK) return update_fail(uc, who, rc);
     std::memcpy(pos, pos_tmp, count * xyz);
     std::memcpy(vel, vel_tmp, count * xyz);
@@ -1309,10 +1344,10 @@ NB_EXPORT int nb_update_instance_boids(float *instances_16n, size_t n_instances,
 }
 
 // update_instance_random (src/main.rs:381-402): three slices, no snapshots; the zip (:386-389) bounds which bodies move.
-NB_EXPORT int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                                        float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step)
+namespace {
+int update_random_common(const char *who, float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                         float *velocities_xyz, size_t n_velocities, bool own_stream, uint64_t seed, uint64_t step)
 {
-    const char *who = "nb_update_instance_random";
     if ((n_positions && !positions_xyz) || (n_velocities && !velocities_xyz) || (n_instances && !instances_16n)) {
         g_tls_error = std::string(who) + ": null array with a nonzero length";
         return NB_ERR_INVALID;
@@ -1327,35 +1362,61 @@ NB_EXPORT int nb_update_instance_random(float *instances_16n, size_t n_instances
     nb_default_params(&p);
     UpdateCache &uc = update_cache();
     std::lock_guard<std::mutex> lock(uc.mu);
-    const uint32_t n = (uint32_t)count;  // every body walks on its own: the device set is exactly the bodies that move
-    if (!uc.ctx || uc.ctx->n != n || std::memcmp(&uc.p, &p, sizeof(p)) != 0) {
-        if (uc.ctx) nb_destroy(uc.ctx);
-        uc.ctx = nullptr;
-        int rc = nb_create(n, 1, &p, &uc.ctx);
-        if (rc != NB_OK) return update_fail(uc, who, rc);
-        uc.p = p;
+    if (own_stream) {  // the three-slice form: the library keeps the seed and counts the calls
+        seed = uc.random_seed;
+        step = uc.random_calls;
     }
-    int rc;
+    const uint32_t n = (uint32_t)count;  // every body walks on its own: the device set is exactly the bodies that move
+    nb_ctx *ctx = nullptr;
+    int rc = update_context(uc, 2, n, p, &ctx);
+    if (rc != NB_OK) return update_fail(uc, who, rc);
     if (n <= kRoundtripMax) {
-        rc = update_roundtrip(uc.ctx, 2, nullptr, positions_xyz, velocities_xyz, count, positions_xyz, velocities_xyz, instances_16n, seed, step);
+        rc = update_roundtrip(ctx, 2, nullptr, positions_xyz, velocities_xyz, count, positions_xyz, velocities_xyz, instances_16n, seed, step);
     } else {
-        rc = nb_upload(uc.ctx, positions_xyz, velocities_xyz);
+        rc = nb_upload(ctx, positions_xyz, velocities_xyz);
         if (rc == NB_OK) {
-            uc.ctx->steps = step;
-            rc = nb_step_random(uc.ctx, 1, seed);
+            ctx->steps = step;
+            rc = nb_step_random(ctx, 1, seed);
         }
-        if (rc == NB_OK) rc = nb_download(uc.ctx, positions_xyz, velocities_xyz, instances_16n);
+        if (rc == NB_OK) rc = nb_download(ctx, positions_xyz, velocities_xyz, instances_16n);
     }
     if (rc != NB_OK) return update_fail(uc, who, rc);
+    if (own_stream) uc.random_calls++;
     return NB_OK;
+}
+}  // namespace
+
+NB_EXPORT int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                        float *velocities_xyz, size_t n_velocities)
+{
+    return update_random_common("nb_update_instance_random", instances_16n, n_instances, positions_xyz, n_positions, velocities_xyz,
+                                n_velocities, true, 0, 0);
+}
+
+NB_EXPORT int nb_update_instance_random_seeded(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
+                                               float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step)
+{
+    return update_random_common("nb_update_instance_random_seeded", instances_16n, n_instances, positions_xyz, n_positions,
+                                velocities_xyz, n_velocities, false, seed, step);
+}
+
+NB_EXPORT void nb_update_random_seed(uint64_t seed)
+{
+    UpdateCache &uc = update_cache();
+    std::lock_guard<std::mutex> lock(uc.mu);
+    uc.random_seed = seed;
+    uc.random_calls = 0;
 }
 
 NB_EXPORT void nb_update_release(void)
 {
     UpdateCache &uc = update_cache();
     std::lock_guard<std::mutex> lock(uc.mu);
-    if (uc.ctx) nb_destroy(uc.ctx);
-    uc.ctx = nullptr;
+    for (UpdateSlot &sl : uc.slot) {
+        if (sl.ctx) nb_destroy(sl.ctx);
+        sl = UpdateSlot();
+    }
+    uc.last = nullptr;
     uc.pos_full = std::vector<float>();
     uc.vel_full = std::vector<float>();
     uc.tmp = std::vector<float>();
@@ -1579,6 +1640,14 @@ NB_EXPORT int nb_launch_status(void *stream)
 {
     int rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
+    if (stream) {  // the status word is per device: ask about the device the stream belongs to, not whichever is current
+        hipDevice_t sdev = -1;
+        int cur = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && sdev >= 0 && sdev != cur)
+            (void)hipSetDevice(sdev);
+        else
+            (void)hipGetLastError();
+    }
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) {
         g_tls_error = std::string("nb_launch_status: hipStreamSynchronize failed: ") + hipGetErrorString(e);
@@ -1613,6 +1682,47 @@ int make_phase_plan(const nb_params &p, uint32_t n_total, uint32_t count, uint32
         uint32_t tile = out->base.tile;
         fast_split(out->len[ph], count, out->base.ib, out->base.waves, &tile, &out->groups[ph], &out->slices[ph], &out->chunk[ph]);
     }
+    return NB_OK;
+}
+}  // namespace
+
+namespace {
+// as cached_plan: a rank asks for the same two phases every step
+int cached_phase_plan(const nb_params &p, uint32_t n_total, uint32_t count, uint32_t j_lo, uint32_t j_hi, const PhasePlan **out,
+                      std::string *err)
+{
+    struct Entry {
+        bool valid = false;
+        nb_params p{};
+        uint32_t n_total = 0, count = 0, j_lo = 0, j_hi = 0, generation = 0;
+        PhasePlan pp{};
+    };
+    constexpr int kEntries = 2;
+    thread_local Entry cache[kEntries];
+    thread_local int next = 0;
+    const uint32_t gen = overrides().generation;
+    for (int i = 0; i < kEntries; ++i) {
+        const Entry &e = cache[i];
+        if (e.valid && e.n_total == n_total && e.count == count && e.j_lo == j_lo && e.j_hi == j_hi && e.generation == gen &&
+            std::memcmp(&e.p, &p, sizeof(p)) == 0) {
+            *out = &e.pp;
+            return NB_OK;
+        }
+    }
+    PhasePlan pp;
+    int rc = make_phase_plan(p, n_total, count, j_lo, j_hi, &pp, err);
+    if (rc != NB_OK) return rc;
+    Entry &e = cache[next];
+    next = (next + 1) % kEntries;
+    e.valid = true;
+    e.p = p;
+    e.n_total = n_total;
+    e.count = count;
+    e.j_lo = j_lo;
+    e.j_hi = j_hi;
+    e.generation = gen;
+    e.pp = pp;
+    *out = &e.pp;
     return NB_OK;
 }
 }  // namespace
@@ -1704,16 +1814,58 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
         g_tls_error = "nb_launch_step_phase: [first, first+count) exceeds n_total";
         return NB_ERR_INVALID;
     }
-    PhasePlan pp;
-    int rc = make_phase_plan(p, n_total, count, j_lo, j_hi, &pp, &g_tls_error);
+    const PhasePlan *ppp = nullptr;
+    int rc = cached_phase_plan(p, n_total, count, j_lo, j_hi, &ppp, &g_tls_error);
     if (rc != NB_OK) return rc;
+    const PhasePlan &pp = *ppp;
     if (scratch_bytes < (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4)) {
         g_tls_error = "nb_launch_step_phase: scratch smaller than nb_scratch_bytes_phased()";
         return NB_ERR_INVALID;
     }
     rc = check_device(&g_tls_error);
     if (rc != NB_OK) return rc;
+    if (!stream) {  // as nb_launch_step: the NULL stream says nothing about the device, the buffers do
+        rc = select_device_of(pos_in, &g_tls_error);
+        if (rc != NB_OK) return rc;
+    }
     return launch_phase_planned(p, pp, n_total, first, count, j_lo, phase, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+NB_EXPORT int nb_diag_rccl_solo(int on)
+{
+    g_rccl_solo.store(on != 0, std::memory_order_relaxed);
+    return NB_OK;
+}
+
+// The kernels one step of this shape launches, dominant one first, as the library itself plans it (bench.py labels its
+// roofline with this instead of restating make_plan).
+NB_EXPORT int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t count, char *out, size_t out_bytes)
+{
+    if (!out || out_bytes == 0) {
+        g_tls_error = "nb_diag_plan: out is null";
+        return NB_ERR_INVALID;
+    }
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    Plan pl;
+    int rc = make_plan(p, n_total, count, &pl, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    std::string k;
+    if (p.mode == NB_MODE_STRICT)
+        k = pl.bc ? "step_strict_bc_kernel,planes_kernel" : pl.pc ? "step_strict_pc_kernel" : "step_strict_kernel";
+    else if (pl.sym)
+        k = "step_fast_sym_kernel,integrate_partials_kernel";
+    else
+        k = std::string(pl.waves ? "step_fast_wave_kernel" : "step_fast_kernel") + (pl.slices > 1 ? ",integrate_partials_kernel" : "");
+    if (k.size() + 1 > out_bytes) {
+        g_tls_error = "nb_diag_plan: out too small";
+        return NB_ERR_INVALID;
+    }
+    std::memcpy(out, k.c_str(), k.size() + 1);
+    return NB_OK;
 }
 
 NB_EXPORT int nb_debug_reload_env(void)

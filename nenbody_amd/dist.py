@@ -55,8 +55,9 @@ class HipBackend:
         stream = torch.cuda.current_stream(pos_in.device).cuda_stream
         sp = scratch.data_ptr() if scratch is not None and scratch.numel() else None
         sb = scratch.numel() if scratch is not None else 0
-        check(self.lib.nb_launch_step(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
-                                      vel.data_ptr(), sp, sb, stream))
+        with torch.cuda.device(pos_in.device):   # the launch and the device status word belong to the buffers' device
+            check(self.lib.nb_launch_step(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
+                                          vel.data_ptr(), sp, sb, stream))
 
     def scratch_bytes_phased(self, params: NbParams, n_total: int, count: int, j_lo: int, j_hi: int) -> int:
         return int(self.lib.nb_scratch_bytes_phased(ctypes.byref(params), n_total, count, j_lo, j_hi))
@@ -66,8 +67,9 @@ class HipBackend:
         import torch
 
         stream = torch.cuda.current_stream(pos_in.device).cuda_stream
-        check(self.lib.nb_launch_step_phase(ctypes.byref(params), n_total, first, count, j_lo, j_hi, phase, pos_in.data_ptr(),
-                                            pos_out.data_ptr(), vel.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+        with torch.cuda.device(pos_in.device):
+            check(self.lib.nb_launch_step_phase(ctypes.byref(params), n_total, first, count, j_lo, j_hi, phase, pos_in.data_ptr(),
+                                                pos_out.data_ptr(), vel.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
 
     def instances(self, count, pos, vel, inst) -> None:
         import torch
@@ -226,7 +228,8 @@ class ShardedScene:
         if self.device.type == "cuda":
             self.torch.cuda.synchronize(self.device)
             if self.backend.name == "hip":
-                check(self.backend.lib.nb_launch_status(self.torch.cuda.current_stream(self.device).cuda_stream))
+                with self.torch.cuda.device(self.device):
+                    check(self.backend.lib.nb_launch_status(self.torch.cuda.current_stream(self.device).cuda_stream))
 
     # -- state access -------------------------------------------------------------------------------------
     def positions(self) -> np.ndarray:
@@ -320,6 +323,14 @@ class NativeShard:
     def _check(self, rc: int) -> None:
         if rc != _lib.NB_OK:
             raise _lib.NbError(rc, self._lib.nb_shard_last_error(self._sh).decode())
+
+    def upload(self, positions, velocities) -> None:
+        """Replaces the state (all n positions, all n velocities; the rank keeps its own range of the latter)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        vel = np.ascontiguousarray(velocities, dtype=np.float32)
+        if pos.shape != (self.n, 3) or vel.shape != (self.n, 3):
+            raise ValueError("positions and velocities must both have shape (n, 3)")
+        self._check(self._lib.nb_shard_upload(self._sh, pos.ctypes.data, vel.ctypes.data))
 
     def step(self, k: int = 1) -> None:
         self._check(self._lib.nb_shard_step(self._sh, int(k)))

@@ -232,11 +232,7 @@ def update_instance_nbody(instances, positions, old_positions, velocities, old_v
     _update_call(_lib.load().nb_update_instance_nbody, instances, positions, old_positions, velocities, old_velocities, params)
 
 
-def update_instance_random(instances, positions, velocities, seed: int = 0, step: int = 0) -> None:
-    """The reference's third controller with its own three arguments, updated in place (src/main.rs:381-385): every body's
-    velocity takes a small random kick in x and y, the position follows, the matrix is rebuilt; `zip` stops at the shortest of
-    the three (main.rs:386-389).  The reference draws from an unseeded ``thread_rng``; here body n at call ``step`` draws from
-    the counter-based stream (seed, step, n), so a run is reproducible.  One call of ``nb_update_instance_random``."""
+def _random_args(instances, positions, velocities):
     for name, arr, tail in (("instances", instances, (4, 4)), ("positions", positions, (3,)), ("velocities", velocities, (3,))):
         if not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.flags.c_contiguous and arr.flags.writeable):
             raise TypeError(f"{name} must be a writable C-contiguous float32 numpy array")
@@ -245,9 +241,29 @@ def update_instance_random(instances, positions, velocities, seed: int = 0, step
     args = []
     for arr in (instances, positions, velocities):
         args += [arr.ctypes.data if len(arr) else None, len(arr)]
-    check(_lib.load().nb_update_instance_random(*args, int(seed), int(step)))
+    return args
+
+
+def update_instance_random(instances, positions, velocities) -> None:
+    """The reference's third controller with its own three arguments, updated in place (src/main.rs:381-385): every body's
+    velocity takes a small random kick in x and y, the position follows, the matrix is rebuilt; `zip` stops at the shortest of
+    the three (main.rs:386-389).  The reference draws from an unseeded ``thread_rng``; here body n at the k-th call draws from
+    the counter-based stream (seed, k, n), seed and call counter kept by the library (:func:`update_random_seed` sets the
+    seed and restarts the counter), so a run is reproducible.  One call of ``nb_update_instance_random``."""
+    check(_lib.load().nb_update_instance_random(*_random_args(instances, positions, velocities)))
+
+
+def update_instance_random_seeded(instances, positions, velocities, seed: int = 0, step: int = 0) -> None:
+    """:func:`update_instance_random` with the stream position given by the caller: body n draws from (seed, step, n).
+    One call of ``nb_update_instance_random_seeded``."""
+    check(_lib.load().nb_update_instance_random_seeded(*_random_args(instances, positions, velocities), int(seed), int(step)))
+
+
+def update_random_seed(seed: int) -> None:
+    """Seed of :func:`update_instance_random`'s stream; restarts its call counter."""
+    _lib.load().nb_update_random_seed(int(seed))
 
 
 def update_release() -> None:
-    """Frees the device context the drop-in functions keep between calls."""
+    """Frees the device contexts the drop-in functions keep between calls."""
     _lib.load().nb_update_release()

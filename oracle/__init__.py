@@ -51,6 +51,11 @@ def load() -> ctypes.CDLL:
         lib.nbo_step_range.restype = None
         lib.nbo_run.argtypes = [vp, vp, vp, u32, u32, f, f, f, i]
         lib.nbo_run.restype = i
+        lib.nbo_run_batched.argtypes = [vp, vp, vp, u32, u32, f, f, f, i]
+        lib.nbo_run_batched.restype = i
+        lib.nbo_step_range_batched.argtypes = [vp, vp, vp, vp, u32, u32, u32, f, f, f]
+        lib.nbo_step_range_batched.restype = None
+        lib.nbo_batched_available.restype = i
         lib.nbo_run_f64.argtypes = [vp, vp, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         lib.nbo_run_f64.restype = i
         lib.nbo_step_range_dv_f64.argtypes = [vp, vp, u32, u32, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -119,14 +124,18 @@ def init_state(n: int, seed: int = 1234):
     return pos, vel
 
 
-def run(pos, vel, k: int, dt=DT, g=G, bias=BIAS, threads: int = 0, want_instances: bool = False):
-    """k applications of update_instance_nbody (main.rs:404-441).  Returns new (pos, vel[, instances])."""
+def run(pos, vel, k: int, dt=DT, g=G, bias=BIAS, threads: int = 0, want_instances: bool = False, batched: bool = False):
+    """k applications of update_instance_nbody (main.rs:404-441).  Returns new (pos, vel[, instances]).
+
+    batched=True runs eight bodies per AVX2 vector (nbo_step_range_batched: the same scalar operations per body, the same
+    bits, several times faster); the default is the scalar loop."""
     p = np.ascontiguousarray(pos, np.float32).copy()
     v = np.ascontiguousarray(vel, np.float32).copy()
     n = len(p)
     inst = np.zeros((n, 4, 4), np.float32) if want_instances else None
-    rc = load().nbo_run(p.ctypes.data, v.ctypes.data, inst.ctypes.data if want_instances else None, n, k, dt, g, bias,
-                        threads or ncores())
+    fn = load().nbo_run_batched if batched else load().nbo_run
+    rc = fn(p.ctypes.data, v.ctypes.data, inst.ctypes.data if want_instances else None, n, k, dt, g, bias,
+            threads or ncores())
     assert rc == 0
     return (p, v, inst) if want_instances else (p, v)
 

@@ -182,6 +182,87 @@ NBO_API void nbo_step_range(const float *old_pos3, float *pos3_out, float *vel3,
     }
 }
 
+/* ------------------------------------------------------------------------------------
+ * The same step, eight bodies at a time (x86 AVX2; anything else takes the loop above).
+ * Each vector lane is one body n and performs exactly the scalar operations of nbo_step_range on
+ * its own operands, in the same order over i (IEEE add / sub / mul / div per lane; no contraction,
+ * no reassociation), so the results are bit-identical by construction; tests/test_oracle.py holds
+ * the two to equality.  It exists because the scalar loop needs hours for the headline size
+ * (N = 131 072, 1 000 steps: tests/golden/make_golden.py --c3); the CPU baseline of bench.py
+ * times the SCALAR loop, which is what the reference's rayon closure compiles to.
+ * ---------------------------------------------------------------------------------- */
+#if defined(__x86_64__)
+typedef float nbo_v8 __attribute__((vector_size(32)));
+
+__attribute__((target("avx2"))) static void step_range_v8(const float *old_pos3, float *pos3_out, float *vel3,
+                                                          uint32_t n_total, uint32_t first, uint32_t count, float dt,
+                                                          float G, float bias)
+{
+    const nbo_v8 vG = {G, G, G, G, G, G, G, G}, vbias = {bias, bias, bias, bias, bias, bias, bias, bias};
+    const nbo_v8 vdt = {dt, dt, dt, dt, dt, dt, dt, dt};
+    for (uint32_t l0 = 0; l0 + 8 <= count; l0 += 8) {
+        nbo_v8 pnx, pny, pnz, sx = {0}, sy = {0}, sz = {0};
+        for (int k = 0; k < 8; ++k) {
+            const size_t n = (size_t)first + l0 + (uint32_t)k;
+            pnx[k] = old_pos3[3 * n + 0];
+            pny[k] = old_pos3[3 * n + 1];
+            pnz[k] = old_pos3[3 * n + 2];
+        }
+        for (uint32_t i = 0; i < n_total; ++i) {
+            const float fx = old_pos3[3 * (size_t)i + 0], fy = old_pos3[3 * (size_t)i + 1], fz = old_pos3[3 * (size_t)i + 2];
+            const nbo_v8 pix = {fx, fx, fx, fx, fx, fx, fx, fx}, piy = {fy, fy, fy, fy, fy, fy, fy, fy},
+                         piz = {fz, fz, fz, fz, fz, fz, fz, fz};
+            const nbo_v8 vx = pix - pnx, vy = piy - pny, vz = piz - pnz; /* main.rs:428 (and the difference inside distance2) */
+            const nbo_v8 xx = vx * vx, yy = vy * vy, zz = vz * vz;
+            const nbo_v8 d2 = (xx + yy) + zz;
+            const nbo_v8 dist = d2 + vbias; /* main.rs:429 */
+            const nbo_v8 gx = vx * vG, gy = vy * vG, gz = vz * vG;
+            sx = sx + gx / dist; /* main.rs:430 */
+            sy = sy + gy / dist;
+            sz = sz + gz / dist;
+        }
+        const nbo_v8 ax = sx * vdt, ay = sy * vdt, az = sz * vdt;
+        for (int k = 0; k < 8; ++k) {
+            float *v = vel3 + 3 * (size_t)(l0 + (uint32_t)k);
+            float *p = pos3_out + 3 * (size_t)(l0 + (uint32_t)k);
+            v[0] = v[0] + ax[k]; /* main.rs:434 */
+            v[1] = v[1] + ay[k];
+            v[2] = v[2] + az[k];
+            p[0] = v[0] + pnx[k]; /* main.rs:436 */
+            p[1] = v[1] + pny[k];
+            p[2] = v[2] + pnz[k];
+        }
+    }
+}
+#endif
+
+/* 1 when nbo_step_range_batched really runs eight bodies per vector on this CPU */
+NBO_API int nbo_batched_available(void)
+{
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
+NBO_API void nbo_step_range_batched(const float *old_pos3, float *pos3_out, float *vel3, float *inst16, uint32_t n_total,
+                                    uint32_t first, uint32_t count, float dt, float G, float bias)
+{
+    uint32_t done = 0;
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) {
+        done = count & ~7u;
+        step_range_v8(old_pos3, pos3_out, vel3, n_total, first, done, dt, G, bias);
+        if (inst16)
+            for (uint32_t l = 0; l < done; ++l)
+                instance_matrix(inst16 + 16 * (size_t)l, pos3_out + 3 * (size_t)l, vel3 + 3 * (size_t)l);
+    }
+#endif
+    nbo_step_range(old_pos3, pos3_out + 3 * (size_t)done, vel3 + 3 * (size_t)done, inst16 ? inst16 + 16 * (size_t)done : NULL,
+                   n_total, first + done, count - done, dt, G, bias);
+}
+
 /* The outer loop over bodies is rayon's par_iter_mut (main.rs:420-424).  Bodies are
  * independent within a step, so the thread count changes scheduling only, never bits.
  * Threads live for the whole run and meet at a barrier twice per step (after the snapshot
@@ -195,6 +276,7 @@ typedef struct {
     float dt, G, bias;
     int tid;
     pthread_barrier_t *bar;
+    int batched;
 } nbo_job;
 
 static void *nbo_worker(void *arg)
@@ -206,8 +288,9 @@ static void *nbo_worker(void *arg)
         if (j->tid == 0) memcpy(j->old_pos3, j->pos3, sizeof(float) * 3 * (size_t)j->n);
         if (j->bar) pthread_barrier_wait(j->bar);
         float *inst = (j->inst16 && s + 1 == j->k) ? j->inst16 + 16 * (size_t)j->first : NULL;
-        nbo_step_range(j->old_pos3, j->pos3 + 3 * (size_t)j->first, j->vel3 + 3 * (size_t)j->first, inst, j->n, j->first,
-                       j->count, j->dt, j->G, j->bias);
+        (j->batched ? nbo_step_range_batched : nbo_step_range)(j->old_pos3, j->pos3 + 3 * (size_t)j->first,
+                                                                j->vel3 + 3 * (size_t)j->first, inst, j->n, j->first,
+                                                                j->count, j->dt, j->G, j->bias);
         if (j->bar) pthread_barrier_wait(j->bar);
     }
     return NULL;
@@ -215,15 +298,15 @@ static void *nbo_worker(void *arg)
 
 /* update_instance_nbody (main.rs:404-441) applied k times.  inst16 may be NULL; when given it
  * holds the matrices of the LAST step, as the caller at main.rs:932-936 would see them. */
-NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, float dt, float G, float bias,
-                    int nthreads)
+static int run_impl(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, float dt, float G, float bias,
+                    int nthreads, int batched)
 {
     float *old = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
     if (!old) return -1;
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > n) nthreads = n ? (int)n : 1;
     if (nthreads == 1) {
-        nbo_job job = {old, pos3, vel3, inst16, n, k, 0, n, dt, G, bias, 0, NULL};
+        nbo_job job = {old, pos3, vel3, inst16, n, k, 0, n, dt, G, bias, 0, NULL, batched};
         nbo_worker(&job);
         free(old);
         return 0;
@@ -235,7 +318,7 @@ NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_
     for (int t = 0; t < nthreads; ++t) {
         uint32_t lo = (uint32_t)(((uint64_t)n * (uint64_t)t) / (uint64_t)nthreads);
         uint32_t hi = (uint32_t)(((uint64_t)n * (uint64_t)(t + 1)) / (uint64_t)nthreads);
-        jobs[t] = (nbo_job){old, pos3, vel3, inst16, n, k, lo, hi - lo, dt, G, bias, t, &bar};
+        jobs[t] = (nbo_job){old, pos3, vel3, inst16, n, k, lo, hi - lo, dt, G, bias, t, &bar, batched};
         pthread_create(&th[t], NULL, nbo_worker, &jobs[t]);
     }
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
@@ -244,6 +327,19 @@ NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_
     free(th);
     free(old);
     return 0;
+}
+
+NBO_API int nbo_run(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, float dt, float G, float bias,
+                    int nthreads)
+{
+    return run_impl(pos3, vel3, inst16, n, k, dt, G, bias, nthreads, 0);
+}
+
+/* nbo_run through nbo_step_range_batched (same bits; see there) */
+NBO_API int nbo_run_batched(float *pos3, float *vel3, float *inst16, uint32_t n, uint32_t k, float dt, float G, float bias,
+                            int nthreads)
+{
+    return run_impl(pos3, vel3, inst16, n, k, dt, G, bias, nthreads, 1);
 }
 
 /* ====================================================================================

@@ -10,10 +10,11 @@ import pytest
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "nenbody.h")
+DIAG_HEADER = os.path.join(ROOT, "include", "nenbody_diag.h")
 
 
-def declared_functions():
-    text = open(HEADER).read()
+def declared_functions(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nb_[a-z_0-9]+)\s*\(", text)))
 
@@ -22,11 +23,14 @@ def test_header_and_binding_declare_the_same_symbols(nb):
     from nenbody_amd import _lib
 
     assert declared_functions() == sorted(_lib.PROTOTYPES)
+    assert declared_functions(DIAG_HEADER) == sorted(_lib.DIAG_PROTOTYPES)
+    # the boundary header declares nothing diagnostic: a host binds only what stands in for the reference's interface
+    assert not [f for f in declared_functions() if f.startswith(("nb_selftest", "nb_debug", "nb_diag"))]
 
 
 def test_library_exports_every_declared_symbol(nb):
     lib = ctypes.CDLL(nb._lib.LIB_PATH)
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions(DIAG_HEADER):
         assert hasattr(lib, name), f"libnenbody_hip.so does not export {name}"
 
 
@@ -336,6 +340,27 @@ def test_camera_constant_is_host_arithmetic_and_matches_the_oracle(oracle):
     assert lib.nb_camera_constant(45.0, 1.0, 1.0, 10.0, None) == _lib.NB_ERR_INVALID
 
 
+def test_camera_constant_known_answer(oracle):
+    """A hand-derived vector neither implementation produced (the library and the oracle share one reading of
+    cgmath).  fovy = 90 degrees, aspect 1, near 1, far 3: f = 1 / tan(45 degrees) = 1, so cgmath::perspective is
+    diag(1, 1, (3+1)/(1-3) = -2, .) with [2][3] = -1 and [3][2] = 2*3*1/(1-3) = -3, and OPENGL_TO_WGPU_MATRIX (gfx.rs:12-17:
+    z' = z/2 + w/2) turns column 2 into (0, 0, -2/2 + -1/2, -1) = (0, 0, -1.5, -1) and column 3 into (0, 0, -3/2, 0): every
+    entry but f exactly representable; f is tan of the binary32 nearest to pi/4, within an ulp of 1."""
+    import nenbody_amd as nb
+
+    for got in (nb.camera_constant(90.0, 1.0, 1.0, 3.0), oracle.camera_constant(90.0, 1.0, 1.0, 3.0)):
+        m = np.asarray(got, np.float32).reshape(4, 4)      # m[k] = column k
+        assert abs(float(m[0, 0]) - 1.0) <= 1.2e-7 and m[1, 1] == m[0, 0]
+        want = np.array([[m[0, 0], 0, 0, 0], [0, m[0, 0], 0, 0], [0, 0, -1.5, -1.0], [0, 0, -1.5, 0]], np.float32)
+        assert (m == want).all(), m
+    # aspect 2 halves [0][0] only; far = 7, near = 1: [2][2] = (8/-6)/2 - 1/2, [3][2] = (14/-6)/2 in binary32
+    m = np.asarray(nb.camera_constant(90.0, 2.0, 1.0, 7.0), np.float32).reshape(4, 4)
+    f = m[1, 1]
+    assert m[0, 0] == f / np.float32(2)
+    assert m[2, 2] == np.float32(0.5) * (np.float32(8) / np.float32(-6)) + np.float32(-0.5) and m[2, 3] == -1
+    assert m[3, 2] == np.float32(0.5) * (np.float32(14) / np.float32(-6)) and m[3, 3] == 0
+
+
 def test_update_instance_random_validates_without_a_device():
     """the argument checks of the third drop-in run before any device is touched: an empty zip is a no-op (main.rs:386-389
     iterates nothing), a null array with a nonzero length is an error, and a real call without a GPU fails loudly"""
@@ -344,9 +369,11 @@ def test_update_instance_random_validates_without_a_device():
 
     lib = nb.load()
     p = np.zeros((4, 3), np.float32)
-    assert lib.nb_update_instance_random(None, 0, p.ctypes.data, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_OK
-    assert lib.nb_update_instance_random(p.ctypes.data, 1, None, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_ERR_INVALID
-    assert "null array" in _lib.last_error()
-    if lib.nb_device_count() == 0:
-        inst = np.zeros((4, 4, 4), np.float32)
-        assert lib.nb_update_instance_random(inst.ctypes.data, 4, p.ctypes.data, 4, p.ctypes.data, 4, 1, 2) == _lib.NB_ERR_NO_DEVICE
+    inst = np.zeros((4, 4, 4), np.float32)
+    for fn, tail in ((lib.nb_update_instance_random, ()), (lib.nb_update_instance_random_seeded, (1, 2))):
+        assert fn(None, 0, p.ctypes.data, 4, p.ctypes.data, 4, *tail) == _lib.NB_OK
+        assert fn(p.ctypes.data, 1, None, 4, p.ctypes.data, 4, *tail) == _lib.NB_ERR_INVALID
+        assert "null array" in _lib.last_error()
+        if lib.nb_device_count() == 0:
+            assert fn(inst.ctypes.data, 4, p.ctypes.data, 4, p.ctypes.data, 4, *tail) == _lib.NB_ERR_NO_DEVICE
+    lib.nb_update_random_seed(5)   # host-side state only

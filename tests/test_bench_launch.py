@@ -1,0 +1,48 @@
+"""bench.py --gpus N started bare: it must start its own N ranks (the driver's N = 1 command was
+`python3 bench.py --gpus 1 ...`; the same shape at N > 1 used to exit before touching a GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bare_gpus_2_starts_two_ranks_and_propagates_their_exit_code():
+    """No GPU here: every rank ends with 'bench.py needs a HIP device', and the parent must report that failure (non-zero)
+    instead of the old 'WORLD_SIZE=1' refusal.  The parent itself never imports torch."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the -m gpu rehearsal below runs the real thing")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a HIP device" in r.stderr
+    assert "WORLD_SIZE=1" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_rehearsal_prints_one_json_line():
+    """Exactly the driver's command shape at N = 2, on the one GPU of the test box: two ranks share the device and exchange
+    through gloo (NB_BENCH_BACKEND=gloo), which the line must own up to in `data`.  No scaling number is claimed."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert "REHEARSAL" in line["data"]
+    assert line["scaling"] == "strong" and line["value"] > 0
+    assert "sharding" in line["config"] and "x2" in line["config"]["sharding"]

@@ -96,6 +96,41 @@ def test_failing_host_exchange_fails_the_step(nb, oracle):
         assert ei.value.status == _lib.NB_ERR_STATE
 
 
+def test_upload_after_overlapped_steps_waits_for_the_exchange_in_flight(nb, oracle):
+    """with nb_shard_set_overlap on, nb_shard_step returns while the all-gather of the new positions is
+    still running on the second stream; after an even number of steps it writes into pos[0], the buffer nb_shard_upload packs
+    the new state into.  Here the host-supplied exchange is asynchronous and SLOW (a long fill ahead of the copy that lands
+    the other rank's slot, all on the stream the library hands over) and lands poison: an upload that does not join the
+    exchange is overwritten by it."""
+    import torch
+
+    n, world = 4096, 2
+    pos, vel = state3d(oracle, n, seed=11)
+    pos2, vel2 = state3d(oracle, n, seed=12)
+    ballast = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    hip = _hip_runtime()
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetAsync.restype = ctypes.c_int
+    landed = []
+
+    def slow_async_gather(buf, slot_bytes, rank, world_, stream):
+        for _ in range(8):      # a few milliseconds of work ahead of the landing copy, on the exchange's stream
+            assert hip.hipMemsetAsync(ballast.data_ptr(), 0, ballast.numel(), stream) == 0
+        other = buf + (1 - rank) * slot_bytes
+        assert hip.hipMemsetAsync(other, 0xFF, slot_bytes, stream) == 0   # all-ones words: NaN records
+        landed.append(slot_bytes)
+
+    with nb.NativeShard(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST), rank=0, world=world, gather=slow_async_gather,
+                        overlap=True) as sh:
+        sh.step(2)              # even: the exchange in flight targets pos[0]
+        sh.upload(pos2, vel2)
+        got = sh.positions()
+        got_v = sh.local_velocities()
+    assert len(landed) == 2
+    assert_bits_equal(got, pos2, "the re-uploaded replica (the old exchange must not land on it)")
+    assert_bits_equal(got_v, vel2[:sh.count], "the re-uploaded velocities")
+
+
 # -- worlds of 2 and 3 as processes on the one GPU, exchange = gloo through the host ------------------------------------
 def _hip_runtime():
     """The HIP runtime already in the process (nenbody_amd preloads it globally), for raw memcpy on device pointers."""

@@ -187,6 +187,87 @@ def test_strict_config2_n16384_long_horizons_vs_golden(nb):
             assert np.bitwise_xor.reduce(bits(v).ravel()) == g[f"n16384_k{k}_xor"][1], f"k={k}: some velocity bit differs"
 
 
+def test_config2_as_written_lds_tile_256(nb, monkeypatch):
+    """BASELINE config 2 literally: "N=16 384 bodies, fp32, 1xMI355X, LDS tile=256, tolerance check vs CPU" -- the one-lane-per-
+    body STRICT kernel staging 256-record tiles through LDS (params.tile = 256; the library's own choice for this size would be
+    the block chain, which has no LDS tile), K = 5 against the golden XOR of every bit; FAST at its default tile of 256."""
+    g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden.npz"))
+    pos, vel = nb.init_state(16384, int(g["seed"][0]))
+    monkeypatch.setenv("NB_STRICT_BC", "0")
+    monkeypatch.setenv("NB_STRICT_PC", "0")
+    monkeypatch.setenv("NB_STRICT_LANES", "1")
+    from nenbody_amd import _lib
+    assert _lib.planned_kernels(nb.default_params(tile=256), 16384, 16384) == ["step_strict_kernel"]
+    with nb.Scene(pos, vel, nb.default_params(tile=256)) as sc:
+        sc.step_n(5)
+        p, v = sc.state()
+    idx = g["n16384_k5_sample_idx"]
+    assert_bits_equal(p[idx], g["n16384_k5_sample_pos"])
+    assert_bits_equal(v[idx], g["n16384_k5_sample_vel"])
+    assert np.bitwise_xor.reduce(bits(p).ravel()) == g["n16384_k5_xor"][0]
+    assert np.bitwise_xor.reduce(bits(v).ravel()) == g["n16384_k5_xor"][1]
+    fast = nb.default_params(mode=nb.NB_MODE_FAST, tile=256)
+    assert _lib.planned_kernels(fast, 16384, 16384)[0] == "step_fast_wave_kernel"
+    with nb.Scene(pos, vel, fast) as sc:
+        sc.step_n(5)
+        pf, vf = sc.state()
+    assert np.abs(pf[idx] - g["n16384_k5_sample_pos"]).max() < 1e-4      # north_star's |dr| bound, at K = 5
+    assert np.abs(vf[idx] - g["n16384_k5_sample_vel"]).max() < 1e-5
+
+
+def _checksums(p, v):
+    pu, vu = bits(p).ravel(), bits(v).ravel()
+    return (np.array([np.bitwise_xor.reduce(pu), np.bitwise_xor.reduce(vu)], dtype=np.uint32),
+            np.array([pu.sum(dtype=np.uint64) & 0xFFFFFFFF, vu.sum(dtype=np.uint64) & 0xFFFFFFFF], dtype=np.uint32))
+
+
+def test_headline_size_through_1000_steps_vs_golden(nb):
+    """The north_star's acceptance line, literally: N = 131 072 (BASELINE config 3, the size bench.py times), the reference's
+    initial distributions and constants, 1 000 steps, positions against the CPU path to |dr| < 1e-4 -- here |dr| = 0: after
+    EVERY one of the 1 000 steps the XOR and the wrapping sum of all position and velocity bit patterns equal the oracle's
+    (tests/golden/nbody_golden_c3.npz, written by make_golden.py --c3), and 64 sampled bodies equal it word for word at
+    K = 1, 40 (the cloud has collapsed), 100 and 1 000.  The data-dependent paths of the kernel (per-tile planarity and range
+    flags, hence ladder or IEEE divide) see the whole evolution, not only the initial uniform square."""
+    g = np.load(os.path.join(GOLDEN_DIR, "nbody_golden_c3.npz"))
+    n = 131072
+    pos, vel = nb.init_state(n, int(g["seed"][0]))
+    idx = g["n131072_sample_idx"]
+    xors, sums, steps = g["n131072_xor"], g["n131072_sum"], g["n131072_steps"]
+    assert len(steps) == 1000 and steps[0] == 1 and steps[-1] == 1000
+    with nb.Scene(pos, vel) as sc:
+        for k in steps:
+            sc.step_n(1)
+            p, v = sc.state()
+            x, s_ = _checksums(p, v)
+            assert (x == xors[k - 1]).all() and (s_ == sums[k - 1]).all(), f"step {k}: the state differs from the oracle's"
+            if f"n131072_k{k}_sample_pos" in g.files:
+                assert_bits_equal(p[idx], g[f"n131072_k{k}_sample_pos"], f"k={k} sampled positions")
+                assert_bits_equal(v[idx], g[f"n131072_k{k}_sample_vel"], f"k={k} sampled velocities")
+                assert int(np.count_nonzero(p[:, 2]) + np.count_nonzero(v[:, 2])) == int(g[f"n131072_k{k}_nonplanar"][0])
+
+
+def test_headline_size_fast_drift_curve(nb, capsys):
+    """FAST at the headline size against STRICT (= the oracle, bit for bit: the test above) step by step through the collapse:
+    what is asserted is what is true -- the drift of one step, and |dr| < 1e-4 (the north_star's bound) for as long as it
+    holds -- and the curve is printed.  FAST cannot track the reference to 1 000 steps: the system is chaotic once the cloud
+    has collapsed, which is what STRICT is for."""
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    curve = []
+    with nb.Scene(pos, vel) as ref, nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as fast:
+        for k in range(1, 61):
+            ref.step_n(1)
+            fast.step_n(1)
+            if k <= 10 or k % 5 == 0:
+                (pr, _), (pf, _) = ref.state(), fast.state()
+                curve.append((k, float(np.abs(pf.astype(np.float64) - pr).max())))
+    with capsys.disabled():
+        print("\n  FAST vs STRICT at N = 131072, max |dr| by step: " + ", ".join(f"{k}: {d:.2e}" for k, d in curve))
+    d = dict(curve)
+    assert d[1] < 2e-5                      # one step: at most a couple of ulps of a coordinate of magnitude 100 (7.6e-6 each)
+    assert d[3] < 1e-4, curve               # the north_star's bound holds for the first steps; the curve says how long
+
+
 def test_strict_ieee_fallback_path_bit_exact(nb, oracle, lanes, monkeypatch):
     """The guarded '/' path (taken when coordinates leave the range where the shared-reciprocal ladder is
     proven exact) must give the same bits; force it for every tile."""
@@ -266,6 +347,20 @@ def test_strict_is_deterministic(nb, oracle):
 # ---------------------------------------------------------------------------------------------------------
 # launch API / sharding (one process, several index ranges): what each rank of a multi-GPU job runs
 # ---------------------------------------------------------------------------------------------------------
+def _oracle_bodies(oracle, pos, vel, idx, consts):
+    """(binary64 velocity change, the reference's binary32 new velocity) of scattered bodies, one step against `pos`: the
+    oracle's scalar loops body by body on a thread pool (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        i = int(i)
+        return oracle.step_range_dv_f64(pos, i, 1, *consts)[0], oracle.step_range(pos, vel[i:i + 1], i, 1)[1][0]
+
+    with ThreadPoolExecutor(max_workers=oracle.ncores()) as pool:
+        out = list(pool.map(one, idx))
+    return np.array([o[0] for o in out]), np.array([o[1] for o in out], np.float32)
+
+
 def _sharded_step_on_one_gpu(nb, pos, vel, parts, params, steps):
     import torch
 
@@ -428,8 +523,30 @@ def test_every_rank_shape_of_configs_4_and_5_vs_oracle(nb, oracle, n, world):
     dv_all = np.abs(vf - vf1).max(axis=1)
     # (both are binary32 sums with their own rounding error -- a whole-set launch at 2^20 bodies does not split j at all and
     # carries a sequential sum's error, like the reference -- so the two may differ by twice the tolerance against the oracle)
-    assert np.quantile(dv_all, 0.999) <= 2 * tol * scale + ulp_v and dv_all.max() <= 1e-3 * scale, msg + f"; all bodies: {dv_all.max():.2e}"
-    assert np.abs(pf - pf1).max() <= dv_all.max() + ulp_p, msg
+    # The evidence for that factor, on the bodies that need it: the 2 048 bodies on which the two FAST launches
+    # differ most plus 2 048 evenly spaced ones, each against the same sum in binary64 and against the reference's own binary32
+    # arithmetic -- neither FAST launch may be further from the binary64 sum than the reference is (plus FAST's stated per-step
+    # tolerance, which covers bodies on which the reference's error happens to cancel).
+    tail = np.argsort(dv_all)[-2048:]
+    chosen = np.unique(np.concatenate([tail, np.linspace(0, n - 1, 2048).astype(np.int64)]))
+    dv64_t, v_ref_t = _oracle_bodies(oracle, pos, vel, chosen, c)
+    v_true_t = vel[chosen].astype(np.float64) + dv64_t
+    err_ref_t = np.abs(v_ref_t.astype(np.float64) - v_true_t).max(axis=1)
+    err_sh_t = np.abs(vf[chosen].astype(np.float64) - v_true_t).max(axis=1)
+    err_one_t = np.abs(vf1[chosen].astype(np.float64) - v_true_t).max(axis=1)
+    in_tail = np.isin(chosen, tail)
+    msg2 = (msg + f"; {len(chosen)} bodies (2 048 with the largest sharded-vs-whole difference, up to {dv_all.max() / scale:.2e}): "
+            f"max |v - v64| / max|dv| on the tail: reference {err_ref_t[in_tail].max() / scale:.2e}, FAST sharded "
+            f"{err_sh_t[in_tail].max() / scale:.2e}, FAST whole set {err_one_t[in_tail].max() / scale:.2e}; medians "
+            f"{np.median(err_ref_t) / scale:.2e} / {np.median(err_sh_t) / scale:.2e} / {np.median(err_one_t) / scale:.2e}")
+    print(msg2)
+    for name, err in (("sharded", err_sh_t), ("whole-set", err_one_t)):
+        assert err.max() <= err_ref_t.max() + ulp_v, f"FAST {name}: " + msg2
+        worst = int(np.argmax(err - err_ref_t))
+        assert (err <= err_ref_t + 2e-5 * scale + ulp_v).all(), (f"FAST {name}, body {chosen[worst]}: {err[worst] / scale:.2e} against the "
+                                                                   f"reference's {err_ref_t[worst] / scale:.2e}; " + msg2)
+    assert np.quantile(dv_all, 0.999) <= 2 * tol * scale + ulp_v and dv_all.max() <= 1e-3 * scale, msg2
+    assert np.abs(pf - pf1).max() <= dv_all.max() + ulp_p, msg2
 
 
 def test_shards_of_a_four_million_body_set_vs_oracle(nb, oracle):

@@ -99,14 +99,25 @@ def test_update_instance_random_operator(nb, oracle, n):
     pos, vel = oracle.init_state(n, 8)
     p, v, inst = pos.copy(), vel.copy(), np.zeros((n, 4, 4), np.float32)
     for step in range(3):
-        nb.update_instance_random(inst, p, v, seed=1234, step=step)
+        nb.update_instance_random_seeded(inst, p, v, seed=1234, step=step)
     pr, vr, ir = oracle.random_run(pos, vel, 3, seed=1234, want_instances=True)
     assert (bits(p) == bits(pr)).all() and (bits(v) == bits(vr)).all()
     assert np.allclose(inst, ir, rtol=0, atol=1e-6)
+    # the reference's own three-argument signature (main.rs:381-385): seed and frame counter live in the library
+    nb.update_random_seed(1234)
+    p3, v3, inst3 = pos.copy(), vel.copy(), np.zeros((n, 4, 4), np.float32)
+    for _ in range(3):
+        nb.update_instance_random(inst3, p3, v3)
+    assert (bits(p3) == bits(pr)).all() and (bits(v3) == bits(vr)).all() and (bits(inst3) == bits(inst)).all()
+    nb.update_random_seed(1234)    # ... and restarting the stream repeats the run
+    p4, v4 = pos.copy(), vel.copy()
+    nb.update_instance_random(inst3, p4, v4)
+    pr1, vr1 = oracle.random_run(pos, vel, 1, seed=1234)
+    assert (bits(p4) == bits(pr1)).all() and (bits(v4) == bits(vr1)).all()
     # a shorter instance slice: only its bodies move; positions and velocities past it keep their bits
     m = n // 3
     p2, v2, inst2 = pos.copy(), vel.copy(), np.zeros((m, 4, 4), np.float32)
-    nb.update_instance_random(inst2, p2, v2, seed=7, step=5)
+    nb.update_instance_random_seeded(inst2, p2, v2, seed=7, step=5)
     pr2, vr2 = oracle.random_run(pos[:m], vel[:m], 1, seed=7, first_step=5)
     assert (bits(p2[:m]) == bits(pr2)).all() and (bits(v2[:m]) == bits(vr2)).all()
     assert (bits(p2[m:]) == bits(pos[m:])).all() and (bits(v2[m:]) == bits(vel[m:])).all()

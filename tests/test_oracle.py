@@ -162,3 +162,21 @@ def test_f64_variant_tracks_f32_over_a_short_horizon(oracle):
     p32, _ = oracle.run(pos, vel, 10)
     p64, _ = oracle.run_f64(pos, vel, 10)
     assert np.abs(p32 - p64).max() < 1e-3
+
+
+@pytest.mark.parametrize("n,k,threads", [(1, 2, 1), (7, 3, 1), (8, 2, 1), (13, 4, 2), (1023, 5, 3), (2051, 2, 2)])
+def test_batched_step_is_the_scalar_loop_bit_for_bit(oracle, n, k, threads):
+    """nbo_step_range_batched (eight bodies per AVX2 vector; what make_golden.py --c3 steps the headline size with) against
+    the scalar restatement of main.rs:424-436: planar and 3-D data, ragged counts, coincident bodies, matrices included."""
+    pos, vel = oracle.init_state(n, 77)
+    rng = np.random.default_rng(n)
+    if n > 8:
+        pos[:, 2] = rng.uniform(-50, 50, n).astype(np.float32)
+        vel[:, 2] = rng.uniform(0, 0.1, n).astype(np.float32)
+        pos[n // 2] = pos[n // 3]                       # a coincident pair: 0 * G / bias
+    a = oracle.run(pos, vel, k, threads=threads, want_instances=True)
+    b = oracle.run(pos, vel, k, threads=threads, want_instances=True, batched=True)
+    for x, y in zip(a, b):
+        assert (bits(x) == bits(y)).all()
+    if not oracle.load().nbo_batched_available():
+        pytest.skip("no AVX2 on this CPU: the batched entry point ran the scalar loop")

@@ -87,8 +87,7 @@ def python_path(mode, exchange=True, overlap=False):
 
 
 def native_path(mode, overlap=False):
-    os.environ["NB_SHARD_RCCL_SOLO"] = "1"
-    nb.reload_env()
+    nb.load().nb_diag_rccl_solo(1)   # a communicator of one rank whatever `world` is (include/nenbody_diag.h)
     sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id(), overlap=overlap)
     sh.step(10)
     sh.sync()
@@ -97,8 +96,7 @@ def native_path(mode, overlap=False):
     sh.sync()
     wall = (time.perf_counter() - t0) / steps
     sh.close()
-    os.environ.pop("NB_SHARD_RCCL_SOLO")
-    nb.reload_env()
+    nb.load().nb_diag_rccl_solo(0)
     return wall
 
 
