@@ -348,25 +348,55 @@ def main():
         try:
             import ctypes
 
-            rates = {}
-            for name, mix in (("fma", 0), ("mix", 1), ("pk_mix", 2)):
-                r = ctypes.c_double()
-                nb._lib.check(nb.load().nb_selftest_valu_rate(mix, 0.05, ctypes.byref(r)))
-                rates[name] = r.value
+            rates, clocks = {}, {}
+            for name, mix in (("fma", 0), ("mix", 1), ("pk_mix", 2), ("fma_distinct_sources", 3), ("fmac_distinct_sources", 4)):
+                r, mhz = ctypes.c_double(), ctypes.c_double()
+                nb._lib.check(nb.load().nb_selftest_valu_rate(mix, 0.05, ctypes.byref(r), ctypes.byref(mhz)))
+                rates[name], clocks[name] = r.value, mhz.value
+            # the clock the part holds under the two folds themselves (stamps inside the kernels: nb_diag_step_clock)
+            held = {}
+            for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
+                mhz, cyc, kms = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+                pm = nb.default_params(mode=mode)
+                nb._lib.check(nb.load().nb_diag_step_clock(ctypes.byref(pm), n, 0.3, ctypes.byref(mhz), ctypes.byref(cyc), ctypes.byref(kms)))
+                held[name] = {"held_clock_mhz": mhz.value, "wave_cycles": cyc.value, "kernel_ms": kms.value}
             ex = line["roofline"]["executed_per_interaction"]
             slots = ex["full_rate_ops"] + 4.0 * ex["v_rcp_f32"]   # a quarter-rate v_rcp_f32 takes the slots of four
             kernel_rate = slots * line["roofline"]["interactions_per_launch"] / (line["roofline"]["kernel_ms"] * 1e-3)
+            simds = 256 * 4
+
+            def cpi(rate, mhz, lane_ops_per_inst=1.0):  # shader cycles per wave-instruction per SIMD at the stamped clock
+                return mhz * 1e6 / (rate / lane_ops_per_inst / 64.0 / simds) if rate > 0 and mhz > 0 else None
+
+            hk = held[args.mode]
             line["roofline"]["measured_issue_ceiling"] = {
                 "fma_stream_tflops": 2.0 * rates["fma"] / 1e12, "fma_stream_frac_of_spec_peak": 2.0 * rates["fma"] / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                 "mix_stream_lane_ops_per_s": rates["mix"], "fma_stream_lane_ops_per_s": rates["fma"],
                 "pk_mix_stream_lane_ops_per_s": rates["pk_mix"],
+                "fma_distinct_sources_lane_ops_per_s": rates["fma_distinct_sources"],
+                "fmac_distinct_sources_lane_ops_per_s": rates["fmac_distinct_sources"],
+                "stream_held_clock_mhz": clocks,
+                "stream_cycles_per_instruction_per_simd": {"fma": cpi(rates["fma"], clocks["fma"]), "mix": cpi(rates["mix"], clocks["mix"]),
+                                                           "pk_mix": cpi(rates["pk_mix"], clocks["pk_mix"], 2.0),
+                                                           "fma_distinct_sources": cpi(rates["fma_distinct_sources"], clocks["fma_distinct_sources"]),
+                                                           "fmac_distinct_sources": cpi(rates["fmac_distinct_sources"], clocks["fmac_distinct_sources"])},
+                "kernels_held_clock": held,
                 "kernel_issue_slots_per_s": kernel_rate, "kernel_over_mix_stream": kernel_rate / rates["mix"],
                 "kernel_over_pk_mix_stream": kernel_rate / rates["pk_mix"],
+                # the same two ratios with the clock taken out: issue slots per shader cycle of the kernel over lane operations per
+                # shader cycle of the stream, each at the clock stamped inside it
+                "kernel_over_mix_stream_per_cycle": (kernel_rate / hk["held_clock_mhz"]) / (rates["mix"] / clocks["mix"]) if hk["held_clock_mhz"] and clocks["mix"] else None,
+                "kernel_over_pk_mix_stream_per_cycle": (kernel_rate / hk["held_clock_mhz"]) / (rates["pk_mix"] / clocks["pk_mix"]) if hk["held_clock_mhz"] and clocks["pk_mix"] else None,
+                "frac_at_held_clock": line["roofline"]["achieved"] / (PEAK_FP32_VECTOR_TFLOPS * hk["held_clock_mhz"] / 2400.0) if hk["held_clock_mhz"] else None,
                 "what": "register-only streams of independent vector instructions on every SIMD (8 waves each), 50 ms each, in this "
-                        "process after the timed legs: v_fma_f32 only (what the spec peak assumes; the part clocks down under it) and "
-                        "the folds' own mix of fma/add/mul/sub, as plain and as packed (v_pk_*, two lane operations each) instructions.  kernel_issue_slots_per_s = interactions/s x the issue slots the "
-                        "kernel executes per interaction (full-rate ops + 4 per v_rcp_f32): kernel_over_mix_stream says how close "
-                        "the kernel runs to what this device issues for that kind of instruction"}
+                        "process after the timed legs: v_fma_f32 only (what the spec peak assumes), the folds' own mix of fma/add/mul/sub as "
+                        "plain and as packed (v_pk_*, two lane operations each) instructions, and v_fma_f32 / v_fmac_f32 with source registers "
+                        "of their own per chain (the plain fma stream shares two sources among its chains).  Every stream and both folds are "
+                        "stamped with s_memtime and s_memrealtime inside the kernel: held_clock_mhz is the shader clock the part held under "
+                        "that code (spec: 2400).  kernel_issue_slots_per_s = interactions/s x the issue slots the kernel executes per "
+                        "interaction (full-rate ops + 4 per v_rcp_f32); kernel_over_*_stream says how close the kernel runs to what this "
+                        "device issues for that kind of instruction, *_per_cycle the same per shader cycle; frac_at_held_clock prices the "
+                        "headline against the spec peak scaled to the clock the kernel was actually given"}
         except Exception as e:  # pragma: no cover
             line["roofline"]["measured_issue_ceiling"] = {"error": repr(e)}
 

@@ -34,9 +34,20 @@ int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
  * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
  * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in
  * the proportion of the pair folds (same issue slots, less power: the part clocks it higher); mix 2: that mix as v_pk_*
- * instructions, two lane-operations each (what the folds mostly issue).  bench.py prints them beside the spec peak its
- * roofline fraction is quoted against. */
-int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s);
+ * instructions, two lane-operations each (what the folds mostly issue); mix 3 / 4: v_fma_f32 / v_fmac_f32 with source
+ * registers of their own per chain (mix 0's eight chains share two sources).  clock_mhz, if non-NULL, receives the shader
+ * clock the stream ran at: the median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped by each
+ * workgroup's first wave at entry and exit.  bench.py prints them beside the spec peak its roofline fraction is quoted against. */
+int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s, double *clock_mhz);
+
+/* Diagnostic: the shader clock the part holds under the whole-set step kernel of `params` (STRICT: step_strict_kernel, one
+ * lane per body; FAST: step_fast_wave_kernel) on n bodies of the reference's initial distribution (seed 1234): back-to-back
+ * steps for about `seconds` (<= 5), the last of them with the kernel's diagnostic stamps switched on (StepArgs::stamps: the
+ * first wave of every workgroup stores s_memtime and s_memrealtime at entry and exit; no output depends on them).
+ * clock_mhz: median over workgroups; wave_cycles (may be NULL): median lifetime of those waves in shader cycles; kernel_ms
+ * (may be NULL): that step by HIP events.  NB_ERR_UNSUPPORTED for shapes that take another kernel. */
+int nb_diag_step_clock(const nb_params *params, uint32_t n, double seconds, double *clock_mhz, double *wave_cycles,
+                       double *kernel_ms);
 
 /* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
  * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,

@@ -132,7 +132,9 @@ DIAG_PROTOTYPES = {
     "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
     "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
-    "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double)]),
+    "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "nb_diag_step_clock": (c_int, [POINTER(NbParams), c_uint32, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                   POINTER(ctypes.c_double)]),
     "nb_debug_reload_env": (c_int, []),
     "nb_diag_rccl_solo": (c_int, [c_int]),
     "nb_diag_plan": (c_int, [POINTER(NbParams), c_uint32, c_uint32, ctypes.c_char_p, c_size_t]),
@@ -191,19 +193,22 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+# the sources that define the kernels bench.py times and profiles/hbm_traffic.json meters (the two whole-set folds, the block
+# chain the shards of a multi-GPU run take, their launchers): NOT the boids controller, the aux kernels, the producer/consumer
+# form, the host-side ABI or anything outside csrc/ -- edits there leave the PMC evidence valid
+BENCHED_KERNEL_SOURCES = ("nb_kernels.hip", "nb_kernels.h", "nb_launch.inc", "nb_nbody_strict.inc", "nb_nbody_fast.inc", "nb_nbody_bc.inc")
+
+
 def kernel_source_sha() -> str:
-    """sha256 (first 16 hex digits) over the KERNEL sources of the library (nb_kernels.hip, nb_kernels.h and the nb_*.inc it
-    includes, launchers included; not the host-side ABI files nb_api.hip / nb_shard.inc), in name order: stamps measurements
+    """sha256 (first 16 hex digits) over BENCHED_KERNEL_SOURCES, in name order: stamps measurements
     (profiles/hbm_traffic.json) with the code they were taken from, so a stale profile is recognised."""
-    import glob
     import hashlib
 
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
-    files = [os.path.join(src, "nb_kernels.hip"), os.path.join(src, "nb_kernels.h")] + glob.glob(os.path.join(src, "nb_*.inc"))
-    for path in sorted(f for f in files if os.path.basename(f) != "nb_shard.inc"):
-        h.update(os.path.basename(path).encode())
-        h.update(open(path, "rb").read())
+    for name in sorted(BENCHED_KERNEL_SOURCES):
+        h.update(name.encode())
+        h.update(open(os.path.join(src, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -44,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -83,6 +83,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->strict_unroll = read_knob("NB_STRICT_UNROLL");
     d->strict_pc = read_knob("NB_STRICT_PC");
     d->strict_bc = read_knob("NB_STRICT_BC");
+    d->strict_sl = read_knob("NB_STRICT_SL");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
     d->boids_pc = read_knob("NB_BOIDS_PC");
     d->boids_tile = read_knob("NB_BOIDS_TILE");
@@ -125,6 +126,7 @@ struct Plan {
     uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
     uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
     uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
+    uint32_t sl;                            // STRICT: 1 = scalar-load form (nb_nbody_sl.inc) instead of the LDS-tiled one-lane kernel; needs scratch
     uint32_t spin_budget;                   // block chain: polls per wait, 0 = kernel default (NB_BC_SPIN_BUDGET: the give-up test)
     uint32_t n_total;                       // the set size the plan was made for
 };
@@ -301,13 +303,19 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= kSmallSet && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     pl.spin_budget = dbg.bc_spin_budget.or_else(0u);
+    // Above the block chain's range (whole sets, shards of more than 65 536 bodies) one lane per body fills the chip, and the
+    // records reach the lanes through scalar loads instead of LDS tiles: no barrier, no ds_read (nb_nbody_sl.inc).  Naming a
+    // tile (params.tile / NB_TILE), a lane count or the producer/consumer form asks for the LDS-tiled kernel; NB_STRICT_SL=0/1 decides outright.
+    pl.sl = dbg.strict_sl.or_else((!pl.bc && !pl.pc && pl.lanes == 1 && p.tile == 0 && !dbg.tile.set && !dbg.strict_lanes.set &&
+                                   !dbg.strict_pc.set && !dbg.strict_unroll.set && !dbg.strict_no_packed.set && n_total >= kSmallSet) ? 1u : 0u);
+    pl.sl = (pl.sl && p.mode == NB_MODE_STRICT && !pl.bc) ? 1u : 0u;
     *out = pl;
     return NB_OK;
 }
 
 size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
-    if (pl.bc) return nbk::strict_bc_scratch_bytes(pl.n_total);
+    if (pl.bc || pl.sl) return nbk::strict_bc_scratch_bytes(pl.n_total);
     if (pl.sym) return (size_t)nbk::fast_sym_rows(pl.n_total, pl.ib, pl.sym) * count * sizeof(float4);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
@@ -510,6 +518,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
         if (sw) status = sw->w;
     }
     hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, status, stream)
+                                                 : pl.sl ? nbk::launch_strict_sl(a, scratch, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : pl.sym   ? (overrides().fast_sym_slp.on() ? nbk::launch_fast_sym_slp(a, pl.ib, pl.sym, stream) : nbk::launch_fast_sym(a, pl.ib, pl.sym, stream))
@@ -1543,10 +1552,33 @@ NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
     return NB_OK;
 }
 
-NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s)
+namespace {
+// The clock a kernel ran at, from the (s_memtime, s_memrealtime) stamps its workgroups' first waves left at entry and exit
+// (4 words per workgroup): median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz -- s_memrealtime ticks at a
+// constant 100 MHz, s_memtime at the shader clock (MI355X_MICROARCH.md, "DVFS give-back" (6)).  Also the median lifetime of
+// those waves in shader cycles.  Workgroups too short to time (< 20 us) are left out.
+bool clock_from_stamps(const std::vector<unsigned long long> &st, double *mhz, double *cycles)
 {
-    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix < 0 || mix > 2)) {
-        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0, 1 or 2 and 0 < seconds <= 2";
+    std::vector<double> f, c;
+    for (size_t i = 0; i + 3 < st.size(); i += 4) {
+        const unsigned long long t0 = st[i], r0 = st[i + 1], t1 = st[i + 2], r1 = st[i + 3];
+        if (r1 <= r0 + 2000ull || t1 <= t0) continue;
+        f.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);
+        c.push_back((double)(t1 - t0));
+    }
+    if (f.empty()) return false;
+    std::sort(f.begin(), f.end());
+    std::sort(c.begin(), c.end());
+    *mhz = f[f.size() / 2];
+    *cycles = c[c.size() / 2];
+    return true;
+}
+}  // namespace
+
+NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s, double *clock_mhz)
+{
+    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix < 0 || mix > 4)) {
+        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0 .. 4 and 0 < seconds <= 2";
         return NB_ERR_INVALID;
     }
     int rc = check_device(&g_tls_error);
@@ -1555,14 +1587,16 @@ NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_pe
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     float *sink = nullptr;
+    unsigned long long *stamps = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    const uint32_t blocks = (uint32_t)cus * 8u;  // 256 lanes = one wave per SIMD each: 8 waves per SIMD
     if (e == hipSuccess) e = hipMalloc((void **)&sink, 64);
+    if (e == hipSuccess && clock_mhz) e = hipMalloc((void **)&stamps, (size_t)blocks * 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    const uint32_t blocks = (uint32_t)cus * 8u;  // 256 lanes = one wave per SIMD each: 8 waves per SIMD
     auto timed = [&](uint32_t trips, float *ms) {
         hipError_t x = hipEventRecord(e0, nullptr);
-        if (x == hipSuccess) x = nbk::launch_valu_stream(mix, blocks, trips, sink, nullptr);
+        if (x == hipSuccess) x = nbk::launch_valu_stream(mix, blocks, trips, sink, stamps, nullptr);
         if (x == hipSuccess) x = hipEventRecord(e1, nullptr);
         if (x == hipSuccess) x = hipEventSynchronize(e1);
         if (x == hipSuccess) x = hipEventElapsedTime(ms, e0, e1);
@@ -1576,7 +1610,14 @@ NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_pe
         trips = (uint32_t)std::min(std::max(want, 1000.0), 4.0e8);
         e = timed(trips, &ms);
     }
+    if (e == hipSuccess && clock_mhz) {
+        std::vector<unsigned long long> st((size_t)blocks * 4);
+        e = hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double cycles = 0.0;
+        if (e == hipSuccess && !clock_from_stamps(st, clock_mhz, &cycles)) *clock_mhz = 0.0;
+    }
     if (sink) (void)hipFree(sink);
+    if (stamps) (void)hipFree(stamps);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess || !(ms > 0.f)) {
@@ -1585,6 +1626,108 @@ NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_pe
     }
     // 64 instructions per trip and lane; a packed instruction (mix 2) is two lane operations
     *lane_ops_per_s = (mix == 2 ? 128.0 : 64.0) * (double)trips * 256.0 * (double)blocks / ((double)ms * 1e-3);
+    return NB_OK;
+}
+
+// The clock the part holds under the whole-set step kernel of `params` (step_strict_kernel / step_fast_wave_kernel) on n
+// bodies of the reference's initial distribution: back-to-back steps for about `seconds`, the last one stamped.
+NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double seconds, double *clock_mhz, double *wave_cycles,
+                                 double *kernel_ms)
+{
+    if (!clock_mhz || !(seconds > 0.0) || seconds > 5.0 || n == 0) {
+        g_tls_error = "nb_diag_step_clock: need clock_mhz != NULL, n > 0 and 0 < seconds <= 5";
+        return NB_ERR_INVALID;
+    }
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    Plan pl;
+    int rc = make_plan(p, n, n, &pl, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    if ((p.mode == NB_MODE_STRICT && (pl.bc || pl.pc || pl.lanes != 1)) || (p.mode == NB_MODE_FAST && (pl.sym || !pl.waves))) {
+        g_tls_error = "nb_diag_step_clock: only the whole-set kernels carry stamps (STRICT one lane per body, FAST wave form)";
+        return NB_ERR_UNSUPPORTED;
+    }
+    nb_ctx *c = nullptr;
+    rc = nb_create(n, 1, &p, &c);
+    if (rc != NB_OK) return rc;
+    std::vector<float> pos((size_t)n * 3), vel((size_t)n * 3);
+    nb_init_state(1234, n, pos.data(), vel.data());
+    rc = nb_upload(c, pos.data(), vel.data());
+    const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl ? 64u : 256u) : 64u * pl.ib;
+    const size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
+    unsigned long long *stamps = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipSuccess;
+    float ms = 0.f;
+    if (rc == NB_OK) {
+        e = hipMalloc((void **)&stamps, groups * 4 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(stamps, 0, groups * 4 * sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        // calibrate on two steps, then fill `seconds`
+        if (e == hipSuccess) rc = nb_step(c, 1);
+        if (e == hipSuccess && rc == NB_OK) e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess && rc == NB_OK) rc = nb_step(c, 1);
+        if (e == hipSuccess && rc == NB_OK) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess && rc == NB_OK) e = hipEventSynchronize(e1);
+        if (e == hipSuccess && rc == NB_OK) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && rc == NB_OK && ms > 0.f) {
+            const uint32_t k = (uint32_t)std::min(std::max(seconds * 1e3 / (double)ms, 2.0), 100000.0);
+            rc = nb_step(c, k - 1u);
+            // the stamped step: the same launch with StepArgs::stamps set
+            if (rc == NB_OK) e = hipEventRecord(e0, c->stream);
+            if (rc == NB_OK && e == hipSuccess) {
+                nbk::StepArgs a{};
+                a.pos_in = c->pos[c->cur];
+                a.pos_out = c->pos[c->cur ^ 1];
+                a.vel = c->vel;
+                a.partial = (float4 *)c->scratch;
+                a.n_total = a.count = a.j_count = n;
+                a.dt = p.dt;
+                a.G = p.G;
+                a.bias = p.bias;
+                a.lo_bits = pl.lo_bits;
+                a.hi_bits = pl.hi_bits;
+                a.force_ieee = pl.force_ieee;
+                a.force_3d = pl.force_3d;
+                a.j_chunk = pl.j_chunk;
+                a.no_packed = pl.no_packed;
+                a.hole_lo = 0xffffffffu;
+                a.stamps = stamps;
+                e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, c->scratch, c->stream)
+                                                      : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, c->stream))
+                                             : nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, c->stream);
+            }
+            if (rc == NB_OK && e == hipSuccess) e = hipEventRecord(e1, c->stream);
+            if (rc == NB_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+            if (rc == NB_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        }
+    }
+    double mhz = 0.0, cycles = 0.0;
+    if (rc == NB_OK && e == hipSuccess) {
+        std::vector<unsigned long long> st(groups * 4);
+        e = hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && !clock_from_stamps(st, &mhz, &cycles)) {
+            g_tls_error = "nb_diag_step_clock: no workgroup ran long enough to time";
+            rc = NB_ERR_STATE;
+        }
+    }
+    if (rc != NB_OK && c) g_tls_error = c->err.empty() ? g_tls_error : c->err;
+    if (stamps) (void)hipFree(stamps);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    nb_destroy(c);
+    if (rc != NB_OK) return rc;
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_diag_step_clock: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    *clock_mhz = mhz;
+    if (wave_cycles) *wave_cycles = cycles;
+    if (kernel_ms) *kernel_ms = (double)ms;
     return NB_OK;
 }
 
@@ -1855,7 +1998,7 @@ NB_EXPORT int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t c
     if (rc != NB_OK) return rc;
     std::string k;
     if (p.mode == NB_MODE_STRICT)
-        k = pl.bc ? "step_strict_bc_kernel,planes_kernel" : pl.pc ? "step_strict_pc_kernel" : "step_strict_kernel";
+        k = pl.bc ? "step_strict_bc_kernel,planes_kernel" : pl.sl ? "step_strict_sl_kernel,planes_kernel" : pl.pc ? "step_strict_pc_kernel" : "step_strict_kernel";
     else if (pl.sym)
         k = "step_fast_sym_kernel,integrate_partials_kernel";
     else

@@ -25,6 +25,10 @@ struct StepArgs {
     uint32_t j_count, j_base, hole_lo, hole_len;
     uint32_t partial_row0;      // FAST: first row of a.partial this launch writes
     uint32_t always_partial;    // FAST: 1 = write partial sums even when gridDim.y == 1 (a later launch integrates)
+    // Diagnostic (nb_diag_step_clock only; NULL in every product launch): the first wave of each workgroup of the whole-set
+    // kernels stores (s_memtime, s_memrealtime) at entry and exit, 4 words per workgroup: the clock the part holds under
+    // THIS kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  No output depends on it.
+    unsigned long long *stamps;
 };
 
 // Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
@@ -52,6 +56,11 @@ hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s
 // `status`: a device word the kernel ORs 1 into when a wave gave up waiting (outputs poisoned): the host's sticky error
 hipError_t launch_strict_bc(const StepArgs &a, void *scratch, uint32_t *status, hipStream_t s);
 size_t strict_bc_scratch_bytes(uint32_t n_total);
+// scalar-load form (nb_nbody_sl.inc): one wave per 64 bodies reads x / y / z planes with scalar loads; same scratch as the block chain
+hipError_t launch_strict_sl(const StepArgs &a, void *scratch, hipStream_t s);
+// the kernel alone (nb_kernels.hip -DNBK_SL_TU): flags / planes as planes_kernel left them
+hipError_t launch_strict_sl_kernel(const StepArgs &a, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
+                                   const float *pz, hipStream_t s);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t groups, uint32_t slices, hipStream_t s);
 hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t waves, uint32_t slices, hipStream_t s);
 // pair-symmetric fold of a whole set (n_total a multiple of 64 * ib); a.partial holds fast_sym_rows() rows of n_total records
@@ -72,7 +81,9 @@ hipError_t launch_ladder_exhaustive(uint32_t first_md, uint32_t count_md, bool c
 // v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for all 2^23 significands m and k in [k_lo, k_hi]
 hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations, hipStream_t s);
 // `blocks` workgroups of 256 lanes each issue trips * 64 register-only vector instructions per lane (mix 0: v_fma_f32; 1: the folds' mix)
-hipError_t launch_valu_stream(int mix, uint32_t blocks, uint32_t trips, float *sink, hipStream_t s);
+// mix 3 / 4: v_fma_f32 / v_fmac_f32 with DISTINCT source registers per chain (mix 0 shares two sources among all eight chains).
+// stamps (may be NULL): 4 words per workgroup, (s_memtime, s_memrealtime) at entry and exit of its first wave
+hipError_t launch_valu_stream(int mix, uint32_t blocks, uint32_t trips, float *sink, unsigned long long *stamps, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

@@ -26,11 +26,13 @@
 // Everything is compiled with -ffp-contract=off: every fused multiply-add is an explicit __builtin_fmaf, every
 // unfused a*b+c stays two roundings.
 //
-// Source layout.  This file is compiled TWICE (Makefile): as is, and with -DNBK_NOSLP_TU -fno-slp-vectorize for the kernels
-// that lose from SLP packing.  The kernels live in per-topic includes:
+// Source layout.  This file is compiled THREE times (Makefile): as is; with -DNBK_NOSLP_TU -fno-slp-vectorize for the kernels
+// that lose from SLP packing; and with -DNBK_SL_TU and the machine scheduler switched off for the scalar-load STRICT kernel,
+// whose source order is its issue order (nb_nbody_sl.inc).  The kernels live in per-topic includes:
 //   nb_nbody_strict.inc  STRICT arithmetic + step_strict_kernel<TJ,U,S>  (S = 1 here; S > 1 "j-parallel" in the SLP-off unit)
 //   nb_nbody_pc.inc      STRICT producer/consumer kernel                  (this unit)
 //   nb_nbody_bc.inc      STRICT block-chain kernel for small shards        (this unit)
+//   nb_nbody_sl.inc      STRICT scalar-load kernel: whole sets and large shards, no LDS, no barrier  (its own unit)
 //   nb_nbody_fast.inc    FAST kernels + fixed-order combine               (this unit; the pair-symmetric kernel: SLP-off unit)
 //   nb_aux.inc           model matrices, cameras, random walk, self-test  (this unit)
 //   nb_boids.inc         boids controller, one-lane and producer/consumer (SLP-off unit)
@@ -51,7 +53,9 @@ static constexpr int kWaves = kBlock / 64;
 
 #include "nb_nbody_strict.inc"  // both translation units: the one-lane form here, the j-parallel shapes in the SLP-off unit
 
-#ifdef NBK_NOSLP_TU
+#if defined(NBK_SL_TU)
+#include "nb_nbody_sl.inc"    // alone in its unit: compiled without the machine scheduler (its source order is its issue order)
+#elif defined(NBK_NOSLP_TU)
 #include "nb_boids.inc"
 #include "nb_nbody_fast.inc"  // for step_fast_sym_kernel only (its rotating sums are DPP operands: packed adds cannot take them)
 #else
@@ -61,6 +65,8 @@ static constexpr int kWaves = kBlock / 64;
 #include "nb_aux.inc"
 #endif
 
+#ifndef NBK_SL_TU
 #include "nb_launch.inc"
+#endif
 
 }  // namespace nbk

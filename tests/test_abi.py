@@ -104,9 +104,12 @@ def test_scratch_bytes_host_arithmetic(nb):
 
     lib = _lib.load()
     strict = nb.default_params()
-    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 0   # STRICT never splits the fold
-    # ... but a small shard of a big set runs the block-chain form, which keeps x / y / z planes of the whole set (+ flags)
+    # STRICT never splits the fold, but both of its large-set forms read x / y / z planes of the whole set (+ flags): the
+    # scalar-load form of whole sets and the block chain of small shards
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 256 + 3 * 4 * 131072
+    tiled = nb.default_params(tile=1024)
+    assert lib.nb_scratch_bytes(ctypes.byref(tiled), 131072, 131072) == 0     # naming an LDS tile asks for the LDS-tiled kernel
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 1000, 1000) == 0          # small sets: producer/consumer, no scratch
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
     b = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
@@ -271,17 +274,28 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
 
     lib = _lib.load()
     tf = ctypes.c_double()
-    assert lib.nb_selftest_valu_rate(0, 0.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_valu_rate(0, 0.05, None) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_valu_rate(1, 5.0, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
-    assert lib.nb_selftest_valu_rate(3, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(0, 0.0, ctypes.byref(tf), None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(0, 0.05, None, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(1, 5.0, ctypes.byref(tf), None) == _lib.NB_ERR_INVALID
+    assert lib.nb_selftest_valu_rate(5, 0.05, ctypes.byref(tf), None) == _lib.NB_ERR_INVALID
+    assert lib.nb_diag_step_clock(None, 131072, 0.1, None, None, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_diag_step_clock(None, 131072, 9.0, ctypes.byref(tf), None, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_diag_step_clock(None, 4096, 0.1, ctypes.byref(tf), None, None) == _lib.NB_ERR_UNSUPPORTED   # block chain: no stamps
+    buf = ctypes.create_string_buffer(8)
+    assert lib.nb_diag_plan(None, 131072, 16384, buf, len(buf)) == _lib.NB_ERR_INVALID and "too small" in _lib.last_error()
+    assert _lib.planned_kernels(nb.default_params(), 131072, 131072) == ["step_strict_sl_kernel", "planes_kernel"]
+    assert _lib.planned_kernels(nb.default_params(tile=1024), 131072, 131072) == ["step_strict_kernel"]
+    assert _lib.planned_kernels(nb.default_params(), 131072, 16384) == ["step_strict_bc_kernel", "planes_kernel"]
+    assert _lib.planned_kernels(nb.default_params(), 1000, 1000) == ["step_strict_kernel"]          # small sets: j-parallel
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_wave_kernel", "integrate_partials_kernel"]
     bad = ctypes.c_uint64()
     assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_rcp_scaling(5, 4, ctypes.byref(bad)) == _lib.NB_ERR_INVALID
     if lib.nb_device_count() > 0:
         pytest.skip("a HIP device is present")
     assert lib.nb_launch_status(None) == _lib.NB_ERR_NO_DEVICE
-    assert lib.nb_selftest_valu_rate(0, 0.05, ctypes.byref(tf)) == _lib.NB_ERR_NO_DEVICE
+    assert lib.nb_selftest_valu_rate(0, 0.05, ctypes.byref(tf), None) == _lib.NB_ERR_NO_DEVICE
+    assert lib.nb_diag_step_clock(None, 131072, 0.1, ctypes.byref(tf), None, None) == _lib.NB_ERR_NO_DEVICE
     # the boids drop-in pads the shorter snapshot on the host before it needs the device
     pos, vel = nb.init_state(12)
     with pytest.raises(nb.NbError) as ei:
