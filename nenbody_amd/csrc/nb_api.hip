@@ -308,7 +308,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     // tile (params.tile / NB_TILE), a lane count or the producer/consumer form asks for the LDS-tiled kernel; NB_STRICT_SL=0/1 decides outright.
     pl.sl = dbg.strict_sl.or_else((!pl.bc && !pl.pc && pl.lanes == 1 && p.tile == 0 && !dbg.tile.set && !dbg.strict_lanes.set &&
                                    !dbg.strict_pc.set && !dbg.strict_unroll.set && !dbg.strict_no_packed.set && n_total >= kSmallSet) ? 1u : 0u);
-    pl.sl = (pl.sl && p.mode == NB_MODE_STRICT && !pl.bc) ? 1u : 0u;
+    pl.sl = (pl.sl && p.mode == NB_MODE_STRICT && !pl.bc) ? std::min(pl.sl, 3u) : 0u;  // NB_STRICT_SL = 1 + launch shape (nb_nbody_sl.inc)
     *out = pl;
     return NB_OK;
 }
@@ -518,7 +518,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
         if (sw) status = sw->w;
     }
     hipError_t e = (p.mode == NB_MODE_STRICT) ? (pl.bc   ? nbk::launch_strict_bc(a, scratch, status, stream)
-                                                 : pl.sl ? nbk::launch_strict_sl(a, scratch, stream)
+                                                 : pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, scratch, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : pl.sym   ? (overrides().fast_sym_slp.on() ? nbk::launch_fast_sym_slp(a, pl.ib, pl.sym, stream) : nbk::launch_fast_sym(a, pl.ib, pl.sym, stream))
@@ -1656,7 +1656,7 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
     std::vector<float> pos((size_t)n * 3), vel((size_t)n * 3);
     nb_init_state(1234, n, pos.data(), vel.data());
     rc = nb_upload(c, pos.data(), vel.data());
-    const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl ? 64u : 256u) : 64u * pl.ib;
+    const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl == 3u ? 64u : 256u) : 64u * pl.ib;
     const size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
     unsigned long long *stamps = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1697,7 +1697,7 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
                 a.no_packed = pl.no_packed;
                 a.hole_lo = 0xffffffffu;
                 a.stamps = stamps;
-                e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, c->scratch, c->stream)
+                e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, c->scratch, c->stream)
                                                       : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, c->stream))
                                              : nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, c->stream);
             }

@@ -57,10 +57,10 @@ hipError_t launch_strict_pc(const StepArgs &a, uint32_t producers, hipStream_t s
 hipError_t launch_strict_bc(const StepArgs &a, void *scratch, uint32_t *status, hipStream_t s);
 size_t strict_bc_scratch_bytes(uint32_t n_total);
 // scalar-load form (nb_nbody_sl.inc): one wave per 64 bodies reads x / y / z planes with scalar loads; same scratch as the block chain
-hipError_t launch_strict_sl(const StepArgs &a, void *scratch, hipStream_t s);
-// the kernel alone (nb_kernels.hip -DNBK_SL_TU): flags / planes as planes_kernel left them
-hipError_t launch_strict_sl_kernel(const StepArgs &a, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
-                                   const float *pz, hipStream_t s);
+hipError_t launch_strict_sl(const StepArgs &a, uint32_t shape, void *scratch, hipStream_t s);
+// the kernel alone (nb_kernels.hip -DNBK_SL_TU): flags / planes as planes_kernel left them; shape: see nb_nbody_sl.inc
+hipError_t launch_strict_sl_kernel(const StepArgs &a, uint32_t shape, const uint32_t *flags, uint32_t generation, const float *px,
+                                   const float *py, const float *pz, hipStream_t s);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t groups, uint32_t slices, hipStream_t s);
 hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t waves, uint32_t slices, hipStream_t s);
 // pair-symmetric fold of a whole set (n_total a multiple of 64 * ib); a.partial holds fast_sym_rows() rows of n_total records

@@ -106,8 +106,8 @@ def test_scratch_bytes_host_arithmetic(nb):
     strict = nb.default_params()
     # STRICT never splits the fold, but both of its large-set forms read x / y / z planes of the whole set (+ flags): the
     # scalar-load form of whole sets and the block chain of small shards
-    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072
-    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 256 + 3 * 4 * 131072
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072 + 64
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 256 + 3 * 4 * 131072 + 64
     tiled = nb.default_params(tile=1024)
     assert lib.nb_scratch_bytes(ctypes.byref(tiled), 131072, 131072) == 0     # naming an LDS tile asks for the LDS-tiled kernel
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 1000, 1000) == 0          # small sets: producer/consumer, no scratch
@@ -234,7 +234,7 @@ def test_debug_overrides_are_read_once_and_reloaded_on_request(nb, monkeypatch):
     monkeypatch.setenv("NB_STRICT_BC", "0")
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 0
     monkeypatch.setenv("NB_STRICT_BC", "1")
-    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072
+    assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 131072) == 256 + 3 * 4 * 131072 + 64
 
 
 def test_plan_arithmetic_over_many_shapes(nb):
@@ -254,7 +254,7 @@ def test_plan_arithmetic_over_many_shapes(nb):
                     elif mode == nb.NB_MODE_FAST:
                         assert b % (count * 16) == 0 and b // (count * 16) <= 64
                     else:
-                        assert b in (0, 256 + 3 * 4 * ((n + 63) // 64 * 64))
+                        assert b in (0, 256 + 3 * 4 * ((n + 63) // 64 * 64) + 64)
     # the repeated call of a rank: same shape, same answer (per-thread plan cache), and a different shape in between
     fake_a, fake_b, fake_v = 0x1000, 0x2000, 0x3000
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
@@ -266,7 +266,7 @@ def test_plan_arithmetic_over_many_shapes(nb):
     odd = nb.default_params()
     for g, bias in ((0.0, 1e-7), (1e-3, 0.0), (float("inf"), 1e-7), (1e-3, float("nan")), (1e38, 1e-38), (1e-38, 1e38), (-1e-3, 1e-7)):
         odd.G, odd.bias = g, bias
-        assert lib.nb_scratch_bytes(ctypes.byref(odd), 131072, 16384) == 256 + 3 * 4 * 131072
+        assert lib.nb_scratch_bytes(ctypes.byref(odd), 131072, 16384) == 256 + 3 * 4 * 131072 + 64
 
 
 def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):

@@ -1310,8 +1310,9 @@ def test_valu_rate_streams_are_sane(nb):
     assert rates[0] < rates[1] <= 1.2 * rates[2] and rates[2] > 0.9 * rates[1], rates
     # the clock each stream was stamped at (s_memtime against the 100 MHz s_memrealtime): a shader clock, at most the 2.4 GHz peak
     assert all(900.0 < c < 2500.0 for c in clocks), clocks
-    # distinct source registers per chain (3) and the VOP2 form (4) issue like the shared-source stream (0): no operand-bank effect
-    assert abs(rates[3] / rates[0] - 1.0) < 0.15 and abs(rates[4] / rates[0] - 1.0) < 0.15, rates
+    # source registers of their own per chain (3) and the VOP2 form (4) issue about 1.5 times as fast as the stream whose eight
+    # chains share two sources (0): the 3.4 cycles per instruction of that stream were an operand-bank effect
+    assert rates[3] > 1.25 * rates[0] and rates[4] > 1.25 * rates[0], rates
 
 
 def test_step_clock_of_the_headline_kernels(nb):
