@@ -63,6 +63,11 @@ hipError_t launch_strict_sl_kernel(const StepArgs &a, uint32_t shape, const uint
                                    const float *py, const float *pz, hipStream_t s);
 hipError_t launch_fast(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t groups, uint32_t slices, hipStream_t s);
 hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint32_t waves, uint32_t slices, hipStream_t s);
+// FAST through scalar loads (nb_nbody_sl.inc): whole-set j range, eight waves per workgroup x slices; scratch = planes area
+// (strict_bc_scratch_bytes) followed by the slices' partial rows
+hipError_t launch_fast_sl(const StepArgs &a, uint32_t ib, uint32_t slices, void *scratch, hipStream_t s);
+hipError_t launch_fast_sl_kernel(const StepArgs &a, uint32_t ib, uint32_t slices, const uint32_t *flags, uint32_t generation,
+                                 const float *px, const float *py, const float *pz, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
 // pair-symmetric fold of a whole set (n_total a multiple of 64 * ib); a.partial holds fast_sym_rows() rows of n_total records
 hipError_t launch_fast_sym(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);      // built without SLP packing
 hipError_t launch_fast_sym_slp(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);  // built with it (measurements)

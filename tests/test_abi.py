@@ -112,7 +112,8 @@ def test_scratch_bytes_host_arithmetic(nb):
     assert lib.nb_scratch_bytes(ctypes.byref(tiled), 131072, 131072) == 0     # naming an LDS tile asks for the LDS-tiled kernel
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 1000, 1000) == 0          # small sets: producer/consumer, no scratch
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
-    b = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384)
+    # FAST at this size reads the planes too (scalar-load form), followed by the rows of partial sums of its grid.y slices
+    b = lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) - (256 + 3 * 4 * 131072 + 64)
     assert b % (16384 * 16) == 0 and 2 <= b // (16384 * 16) <= 64
     assert lib.nb_scratch_bytes(ctypes.byref(fast), 10, 20) == 0             # invalid shape -> 0
 
@@ -222,14 +223,14 @@ def test_debug_overrides_are_read_once_and_reloaded_on_request(nb, monkeypatch):
     try:
         assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == auto
         assert lib.nb_debug_reload_env() == _lib.NB_OK  # ... until it is told to look
-        assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 3 * 16384 * 16
+        assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == (256 + 3 * 4 * 131072 + 64) + 3 * 16384 * 16
     finally:
         del os.environ["NB_FAST_SLICES"]
         lib.nb_debug_reload_env()
     assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == auto
     monkeypatch.setenv("NB_FAST_SLICES", "1")   # the fixture reloads by itself
     monkeypatch.setenv("NB_FAST_GROUPS", "4")
-    assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 0   # the j chunks meet in LDS: nothing through memory
+    assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 0   # (an LDS form, named by its groups) the j chunks meet in LDS: nothing through memory
     strict = nb.default_params()
     monkeypatch.setenv("NB_STRICT_BC", "0")
     assert lib.nb_scratch_bytes(ctypes.byref(strict), 131072, 16384) == 0
@@ -252,7 +253,9 @@ def test_plan_arithmetic_over_many_shapes(nb):
                     if n > 1 << 31:      # refused (32-bit record indices need headroom for padding): no plan, no scratch
                         assert b == 0
                     elif mode == nb.NB_MODE_FAST:
-                        assert b % (count * 16) == 0 and b // (count * 16) <= 64
+                        planes = 256 + 3 * 4 * ((n + 63) // 64 * 64) + 64     # the scalar-load form (sets of 4 096 bodies and more, library's own tile)
+                        rows = b - planes if (tile == 0 and n >= 4096) else b
+                        assert rows >= 0 and rows % (count * 16) == 0 and rows // (count * 16) <= 64
                     else:
                         assert b in (0, 256 + 3 * 4 * ((n + 63) // 64 * 64) + 64)
     # the repeated call of a rank: same shape, same answer (per-thread plan cache), and a different shape in between
@@ -287,7 +290,8 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     assert _lib.planned_kernels(nb.default_params(tile=1024), 131072, 131072) == ["step_strict_kernel"]
     assert _lib.planned_kernels(nb.default_params(), 131072, 16384) == ["step_strict_bc_kernel", "planes_kernel"]
     assert _lib.planned_kernels(nb.default_params(), 1000, 1000) == ["step_strict_kernel"]          # small sets: j-parallel
-    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_wave_kernel", "integrate_partials_kernel"]
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_sl_kernel", "planes_kernel", "integrate_partials_kernel"]
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST, tile=256), 131072, 131072) == ["step_fast_wave_kernel", "integrate_partials_kernel"]
     bad = ctypes.c_uint64()
     assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID
     assert lib.nb_selftest_rcp_scaling(5, 4, ctypes.byref(bad)) == _lib.NB_ERR_INVALID
@@ -315,11 +319,11 @@ def test_committed_hbm_traffic_is_of_the_current_kernel_sources(nb):
 
     t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     assert set(t) >= {"n", "count", "src_sha", "kernels", "source"} and t["n"] == 131072 and t["count"] == 131072
-    for k in ("step_strict_kernel", "step_fast_wave_kernel", "integrate_partials_kernel"):
-        assert t["kernels"][k]["bytes_per_launch"] == t["kernels"][k]["read"] + t["kernels"][k]["write"] > 0
     if t["src_sha"] != _lib.kernel_source_sha():
         pytest.skip("profiles/hbm_traffic.json is stale (kernel sources changed since the PMC passes): re-run tools/profile_bench.sh "
                     "and tools/pmc_summary.py --json")
+    for k in ("step_strict_sl_kernel", "step_fast_sl_kernel", "planes_kernel", "integrate_partials_kernel"):
+        assert t["kernels"][k]["bytes_per_launch"] == t["kernels"][k]["read"] + t["kernels"][k]["write"] > 0
 
 
 def test_camera_constant_is_host_arithmetic_and_matches_the_oracle(oracle):
