@@ -89,6 +89,8 @@ hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations
 // mix 3 / 4: v_fma_f32 / v_fmac_f32 with DISTINCT source registers per chain (mix 0 shares two sources among all eight chains).
 // stamps (may be NULL): 4 words per workgroup, (s_memtime, s_memrealtime) at entry and exit of its first wave
 hipError_t launch_valu_stream(int mix, uint32_t blocks, uint32_t trips, float *sink, unsigned long long *stamps, hipStream_t s);
+// sharded boids: the gathered staging buffer [world][pos slot | vel slot] -> position and velocity replicas (world * slot records each)
+hipError_t launch_unstage(uint32_t slot, uint32_t world, const float4 *stage, float4 *pos, float4 *vel, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

@@ -142,12 +142,14 @@ class ShardedScene:
         self.cur = 0
         self.steps_done = 0
         self.velfull = None      # boids only: replicas of ALL velocities (ping-pong), built on first use
+        self._pvstage = None     # boids, world > 1: [world][pos slot | vel slot], what the one all-gather per step moves
         self.velfull_valid = False
 
     # -- the exchange: every rank contributes its slot of `buf` and receives the others -----------------------
-    def _all_gather_slots(self, buf, async_op: bool = False):
-        lo = self.rank * self.slot
-        mine = buf[lo:lo + self.slot]
+    def _all_gather_slots(self, buf, async_op: bool = False, slot: Optional[int] = None):
+        slot = self.slot if slot is None else slot
+        lo = self.rank * slot
+        mine = buf[lo:lo + slot]
         if self.dist.get_backend(self.group) == "nccl":
             # RCCL, in place: the send buffer is this rank's slot of the receive buffer
             return self.dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op)
@@ -185,11 +187,22 @@ class ShardedScene:
             self.velfull_valid = True
         psrc, pdst = self.pos[self.cur], self.pos[self.cur ^ 1]
         vsrc, vdst = self.velfull[self.cur], self.velfull[self.cur ^ 1]
-        if self.count:
-            self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, pdst, vdst)
         if self.world > 1:
-            self._all_gather_slots(pdst)
-            self._all_gather_slots(vdst)
+            # ONE exchange per step for both outputs: every rank's slot of the staging buffer is [slot position records | slot
+            # velocity records]; the kernel writes this rank's new records straight into its slot (views offset so that record
+            # first + l lands there: first == rank * slot), the slots are gathered in place, and the replicas are dealt out of it
+            if self._pvstage is None:
+                self._pvstage = torch.zeros((self.world * 2 * self.slot, 4), dtype=torch.float32, device=self.device)
+            st = self._pvstage
+            if self.count:
+                self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, st[self.rank * self.slot:],
+                                        st[self.rank * self.slot + self.slot:])
+            self._all_gather_slots(st, slot=2 * self.slot)
+            both = st.view(self.world, 2, self.slot, 4)
+            pdst.view(self.world, self.slot, 4).copy_(both[:, 0])
+            vdst.view(self.world, self.slot, 4).copy_(both[:, 1])
+        elif self.count:
+            self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, pdst, vdst)
         if self.count:
             self.vel[: self.count] = vdst[lo:lo + self.count]  # keep the local velocities current for n-body steps
         self.cur ^= 1

@@ -37,10 +37,23 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False):
         sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap)
         assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap
         if boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
+            gathers = []
+            real = dist.all_gather_into_tensor
+
+            def counting(out, inp, *a, **kw):
+                gathers.append(out.numel())
+                return real(out, inp, *a, **kw)
+
+            dist.all_gather_into_tensor = counting
             sc.step_boids()
             sc.step()
             for _ in range(k):
                 sc.step_boids()
+            dist.all_gather_into_tensor = real
+            # ONE exchange per boids step (positions and velocities in one staging buffer: twice a replica's size), one per n-body
+            # step, and one rebuild of the velocity replica each time boids follows something else
+            slots = world * sc.slot * 4
+            assert gathers == [slots, 2 * slots, slots, slots] + [2 * slots] * k, gathers
         else:
             sc.step_n(k)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities(),

@@ -201,9 +201,9 @@ def test_worlds_of_two_and_three_equal_the_oracle(tmp_path, nb, oracle, world, n
         assert_bits_equal(got["pos"], p_ref, f"rank {r} positions (replica)")
         assert_bits_equal(got["vel"], v_ref[first:first + count], f"rank {r} velocities")
         assert np.allclose(got["inst"], inst_ref[first:first + count], rtol=0, atol=1e-6)
-        # n-body: one exchange per step; boids: positions + velocities per step, + one rebuild of the velocity replica
-        # each time boids follows n-body steps
-        assert int(got["calls"]) == 3 + (1 + 2 * 2) + (1 + 2 * 1)
+        # n-body: one exchange per step; boids: ONE per step too (positions and velocities travel in one staging buffer),
+        # + one rebuild of the velocity replica each time boids follows n-body steps
+        assert int(got["calls"]) == 3 + (1 + 2) + (1 + 1)
         covered += count
     assert covered == n
 

@@ -3,8 +3,8 @@
 # evidence directory DST (profiles/rNN) under stable names, then reduce the PMC passes and stamp profiles/hbm_traffic.json
 # with the hash of the kernel sources (bench.py refuses a stale stamp).  Runs anywhere (no GPU).
 set -eu
-SRC=${1:-gpurun_out/prof_r02}
-DST=${2:-profiles/r02}
+SRC=${1:-gpurun_out/prof_r03}
+DST=${2:-profiles/r03}
 mkdir -p "$DST/pmc"
 for mode in strict fast all; do
     f=$(find "$SRC/stats_$mode" -name "*_kernel_stats.csv" | head -1)
