@@ -48,7 +48,7 @@ def main(root, json_path=None, n=None, count=None, source=None):
             base = re.sub(r"<.*$", "", k.replace("nbk::", ""))
             # several instantiations of one kernel template in a run: keep the one with the most samples (the bench's own shape)
             if base not in traffic or traffic[base]["samples"] < len(dur[k]):
-                traffic[base] = {"bytes_per_launch": int(rd + wr), "read": int(rd), "write": int(wr), "samples": len(dur[k]),
+                traffic[base] = {"bytes_per_launch": int(rd) + int(wr), "read": int(rd), "write": int(wr), "samples": len(dur[k]),
                                  "kernel": k, "mean_ms_under_counters": sum(dur[k]) / len(dur[k])}
         if "SQ_WAVE_CYCLES" in vals and "SQ_ACTIVE_INST_ANY" in vals:
             wc = vals["SQ_WAVE_CYCLES"]
