@@ -44,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, bc_spin_budget, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -86,6 +86,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->strict_sl = read_knob("NB_STRICT_SL");
     d->fast_sl = read_knob("NB_FAST_SL");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
+    d->bc_prio = read_knob("NB_BC_PRIO");
     d->boids_pc = read_knob("NB_BOIDS_PC");
     d->boids_tile = read_knob("NB_BOIDS_TILE");
     d->boids_force = read_knob("NB_BOIDS_FORCE");
@@ -130,6 +131,7 @@ struct Plan {
     uint32_t fsl;                           // FAST: 1 = scalar-load form (step_fast_sl_kernel, nb_nbody_sl.inc): whole-set launches, eight waves per workgroup; needs scratch
     uint32_t sl;                            // STRICT: 1 = scalar-load form (nb_nbody_sl.inc) instead of the LDS-tiled one-lane kernel; needs scratch
     uint32_t spin_budget;                   // block chain: polls per wait, 0 = kernel default (NB_BC_SPIN_BUDGET: the give-up test)
+    uint32_t bc_prio;                       // block chain: raised wave priority around the chain turns (NB_BC_PRIO=0 switches it off)
     uint32_t n_total;                       // the set size the plan was made for
 };
 
@@ -319,6 +321,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= kSmallSet && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     pl.spin_budget = dbg.bc_spin_budget.or_else(0u);
+    pl.bc_prio = dbg.bc_prio.or_else(1u) ? 1u : 0u;
     // Above the block chain's range (whole sets, shards of more than 65 536 bodies) one lane per body fills the chip, and the
     // records reach the lanes through scalar loads instead of LDS tiles: no barrier, no ds_read (nb_nbody_sl.inc).  Naming a
     // tile (params.tile / NB_TILE), a lane count or the producer/consumer form asks for the LDS-tiled kernel; NB_STRICT_SL=0/1 decides outright.
@@ -524,6 +527,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.j_chunk = pl.j_chunk;
     a.no_packed = pl.no_packed;
     a.spin_budget = pl.spin_budget;
+    a.bc_prio = pl.bc_prio;
     a.j_count = n_total;  // the whole set: no base, no hole
     a.j_base = 0;
     a.hole_lo = 0xffffffffu;

@@ -19,6 +19,7 @@ struct StepArgs {
     uint32_t j_chunk;           // FAST: records per j chunk (one per 256-lane group per blockIdx.y slice), a multiple of the tile
     uint32_t no_packed;         // STRICT: 1 = planar tiles take the component-packed fold instead of the j-packed one (tests, measurements)
     uint32_t spin_budget;       // STRICT block chain: polls per wait before a wave gives up; 0 = the default (tests set a tiny one)
+    uint32_t bc_prio;           // STRICT block chain: 1 = the wave that waits for / holds a turn runs at a raised priority
     // FAST, a step in two phases (nb_launch_step_phase): the fold runs over j_count VIRTUAL records, virtual index v being
     // record  j = v + j_base, plus hole_len if that is >= hole_lo  -- a contiguous range of the set, or the set without one.
     // A whole-set launch has j_base = 0, hole_len = 0, j_count = n_total.

@@ -691,6 +691,60 @@ def test_fast_wave_form_every_launch_shape(nb, oracle, monkeypatch, ib, waves, s
         assert np.abs(p - p_ref).max() <= 2e-5, f"n={n}"
 
 
+@pytest.mark.parametrize("ib,slices", [(1, 1), (2, 1), (4, 1), (1, 3), (2, 5), (4, 2), (4, 64)])
+def test_fast_scalar_load_form_every_launch_shape(nb, oracle, monkeypatch, ib, slices):
+    """FAST through scalar loads (step_fast_sl_kernel, what sets of 4 096 bodies and more run): ragged sizes (ranges that
+    start and end anywhere in a 16-record request, sets smaller than one request), planar and 3-D data, with and without the
+    shared reciprocal, a huge-coordinate set that must not share; deterministic run to run."""
+    monkeypatch.setenv("NB_FAST_SL", "1")
+    monkeypatch.setenv("NB_FAST_IB", str(ib))
+    monkeypatch.setenv("NB_FAST_SLICES", str(slices))
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    from nenbody_amd import _lib
+    assert _lib.planned_kernels(fast, 777, 777)[0] == "step_fast_sl_kernel"
+    for n, planar, no_share in ((5000, False, "0"), (64 * ib, False, "0"), (777, True, "0"), (1, True, "0"), (15, False, "0"), (17, True, "1"),
+                                (4099, True, "0"), (2049, False, "1")):
+        monkeypatch.setenv("NB_FAST_NO_SHARE", no_share)
+        pos, vel = state3d(oracle, n, seed=ib * 100 + slices + n)
+        if planar:
+            pos[:, 2] = 0
+            vel[:, 2] = 0
+        outs = []
+        for _ in range(2):
+            with nb.Scene(pos, vel, fast) as sc:
+                sc.step_n(2)
+                outs.append(sc.state())
+        assert_bits_equal(outs[0][0], outs[1][0], "run-to-run determinism")
+        assert_bits_equal(outs[0][1], outs[1][1], "run-to-run determinism (velocities)")
+        p, v = outs[0]
+        p_ref, v_ref = oracle.run(pos, vel, 2)
+        acc = np.abs(v_ref - vel).max()
+        assert np.abs(v - v_ref).max() <= 4e-5 * acc + float(np.spacing(np.abs(v_ref).max())), f"n={n}"
+        assert np.abs(p - p_ref).max() <= 2e-5, f"n={n}"
+    # coordinates of 2^28 and more: the product of two r^2 would overflow; the step's flag must switch sharing off (same bits as forced off)
+    monkeypatch.setenv("NB_FAST_IB", "2")
+    pos, vel = state3d(oracle, 3000, seed=91)
+    pos[5::64] = np.array([3.0e9, -2.5e9, 1.0e9], np.float32) * (1 + np.arange(len(pos[5::64]), dtype=np.float32)[:, None] / 64)
+    got = []
+    for no_share in ("1", "0"):
+        monkeypatch.setenv("NB_FAST_NO_SHARE", no_share)
+        with nb.Scene(pos, vel, fast) as sc:
+            sc.step_n(1)
+            got.append(sc.state())
+    assert np.isfinite(got[0][0]).all() and np.isfinite(got[0][1]).all()
+    assert_bits_equal(got[1][0], got[0][0], "huge coordinates must take the unshared form")
+    assert_bits_equal(got[1][1], got[0][1], "huge coordinates must take the unshared form (velocities)")
+    # through the launch API: shards with first != 0 and ragged counts against the whole-set launch of the same form
+    n = 6000
+    pos, vel = state3d(oracle, n, seed=7)
+    monkeypatch.setenv("NB_FAST_NO_SHARE", "0")
+    monkeypatch.setenv("NB_FAST_SLICES", "1")          # one chunk per wave x 8 waves, the same chunks for every shard: the same sums
+    pw, vw = _sharded_step_on_one_gpu(nb, pos, vel, [(0, n)], fast, 1)
+    ps, vs = _sharded_step_on_one_gpu(nb, pos, vel, [(0, 1), (1, 2047), (2048, 3000), (5048, 952)], fast, 1)
+    assert_bits_equal(ps, pw, "FAST scalar-load form: shards == whole set (same chunks, same order)")
+    assert_bits_equal(vs, vw, "FAST scalar-load form: shards == whole set (velocities)")
+
+
 @pytest.mark.parametrize("n,ib,sym", [(256, 4, 2), (1024, 4, 2), (2048, 4, 4), (4096, 4, 8), (2560, 4, 4), (6400, 4, 8), (1280, 2, 8), (640, 2, 4),
                                       (32768, 4, 4)])
 def test_fast_pair_symmetric_fold(nb, oracle, monkeypatch, n, ib, sym):

@@ -38,9 +38,12 @@ def test_strict_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(1000 + case)
     n = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 257, 700, 1500, 2300]))
     k = int(rng.integers(1, 4))
-    shape = rng.choice(["auto", "lanes1", "lanes2", "lanes4", "lanes8", "lanes16", "pc8", "pc14", "bc"])
+    shape = rng.choice(["auto", "lanes1", "lanes2", "lanes4", "lanes8", "lanes16", "pc8", "pc14", "bc", "sl", "sl"])
     if shape == "bc":
         monkeypatch.setenv("NB_STRICT_BC", "1")
+    elif shape == "sl":       # the scalar-load form whole sets take (nb_nbody_sl.inc), one of its three launch shapes
+        monkeypatch.setenv("NB_STRICT_SL", str(int(rng.integers(1, 4))))
+        monkeypatch.setenv("NB_STRICT_BC", "0")
     elif shape.startswith("pc"):
         monkeypatch.setenv("NB_STRICT_PC", shape[2:])
     elif shape.startswith("lanes"):
@@ -97,7 +100,10 @@ def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
     n = int(rng.choice([64, 300, 1000, 2500, 4000]))
     monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
     monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
-    monkeypatch.setenv("NB_FAST_GROUPS", str(int(rng.choice([1, 2, 4]))))
+    if case % 4 < 2:
+        monkeypatch.setenv("NB_FAST_GROUPS", str(int(rng.choice([1, 2, 4]))))    # an LDS form
+    else:
+        monkeypatch.setenv("NB_FAST_SL", "1")                                    # the scalar-load form
     pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
     vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
     if case % 2 == 0:
