@@ -308,9 +308,10 @@ def main():
                                         "value": n * bsteps / float(bt.item()),
                                         "ms_per_step": 1e3 * float(bt.item()) / bsteps, "steps": bsteps,
                                         "pair_evaluations_per_s": float(n) * n * bsteps / float(bt.item()),
-                                        "executed_per_pair": {"full_rate_ops": 16,
+                                        "executed_per_pair": {"full_rate_ops": 14,
                                                               "note": "planar tiles whose velocities cannot fail the rule-3 test "
-                                                                      "(the reference's constants: every tile); 24 when it is tested"}}
+                                                                      "(the reference's constants: every tile); 21 when it is tested; each "
+                                                                      "radius test is one fma with a clamp"}}
         except Exception as e:  # pragma: no cover
             line["boids_controller"] = {"error": repr(e)}
 

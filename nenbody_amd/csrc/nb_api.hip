@@ -677,6 +677,30 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
         return NB_ERR_UNSUPPORTED;
     }
     a.force_flags = overrides().boids_force.or_else(0u) & 7u;
+    // the radius tests as single instructions (nb_boids.inc:boids_below): `x < T` needs T finite, positive and not tiny, so that
+    // k = 2^(30 - e_T) and T * k are ordinary binary32 numbers; "nothing passes" (T <= 0) is the constant mask 0.  A radius
+    // without such constants switches the masked form off for the step (flag 1: the select form, same bits).
+    auto mask_consts = [](float T, float *k, float *tk) {
+        if (!(T > 0.0f)) {  // T <= 0, -inf or NaN: x < T never holds for x >= 0
+            *k = 0.0f;
+            *tk = -1.0f;
+            return true;
+        }
+        if (!std::isfinite(T) || T < 0x1p-90f) return false;
+        const int e = floor_log2f(T);
+        *k = std::ldexp(1.0f, 30 - e);  // e in [-90, 127]: 2^-97 .. 2^120
+        *tk = T * *k;                   // exact: a power-of-two scaling into [2^30, 2^31)
+        return true;
+    };
+    auto above = [](float t) { return t < 0.0f ? -1.0f : std::nextafter(t, INFINITY); };  // x <= t  <=>  x < above(t)
+    if (!mask_consts(a.r1, &a.mk.k1, &a.mk.tk1) || !mask_consts(above(a.t2), &a.mk.k2, &a.mk.tk2) ||
+        !mask_consts(above(a.t3), &a.mk.k3, &a.mk.tk3)) {
+        a.force_flags |= 1u;
+        a.mk = nbk::BoidsMaskK{0.f, -1.f, 0.f, -1.f, 0.f, -1.f};
+        a.mk_valid = 0u;
+    } else {
+        a.mk_valid = 1u;
+    }
     const float v_lim = rule3_always_bound(a.t3);
     if (v_lim < 0.0f)
         a.force_flags |= 4u;  // no such bound (rule_3_distance <= 0 or NaN): always test

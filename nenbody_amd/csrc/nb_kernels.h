@@ -32,6 +32,14 @@ struct StepArgs {
     unsigned long long *stamps;
 };
 
+// A radius test `x < T` as ONE vector instruction (nb_boids.inc:boids_below): mask = clamp(fma(-x, k, T * k)) with k a power of
+// two chosen by the host so that T * k ~ 2^30: exactly 1.0f where x < T, exactly 0.0f elsewhere (NaN included).
+struct BoidsMaskK {
+    float k1, tk1;  // rule 1:  d2 < rule_1_distance                    (main.rs:474-475)
+    float k2, tk2;  // rule 2:  d2 < the binary32 above t2              (main.rs:485-486: sqrt(d2) < rule_2_distance <=> d2 <= t2)
+    float k3, tk3;  // rule 3:  e2 < the binary32 above t3              (main.rs:497-498)
+};
+
 // Arguments of one boids step (update_instance_boids, main.rs:443-526) for bodies [first, first+count).
 struct BoidsArgs {
     const float4 *pos_in;  // n_total records: old_positions (main.rs:459)
@@ -45,6 +53,8 @@ struct BoidsArgs {
     float s1, s2, s3;      // rule scales, main.rs:454-456
     uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form, 4 = always test rule 3 (tests)
     uint32_t vlim_bits;    // bit pattern of v_lim: velocity components of at most this magnitude cannot fail the rule-3 test (nb_boids.inc, ALL3)
+    uint32_t mk_valid;     // 1 = mk holds usable constants for all three radii (else: dummies, and force_flags bit 1 is set)
+    BoidsMaskK mk;         // the three radius tests as single instructions (masked form only; the host clears the form where a radius has no such constants)
 };
 // form: 0 = one lane per body, 1 = producer/consumer (64 bodies x 16 waves), 2 = one lane per body with (x, y) packed,
 // 3 / 4 = chain split (two waves per 64 bodies: rule 1 | rules 2-3) plain / packed
