@@ -159,6 +159,35 @@ def test_boids_velocity_radius_and_custom_constants(nb, oracle):
         assert_bits_equal(p, p_ref, f"r3={r3} r2={r2} r1={r1}")
 
 
+@pytest.mark.parametrize("pc", ["3", "2", "4", "5"], ids=["lane-per-body", "lane-per-body-packed", "chain-split", "chain-split-packed"])
+def test_boids_one_instruction_radius_tests_at_their_limits(nb, oracle, monkeypatch, pc):
+    """Round 3: a radius test `d2 < T` is one instruction, clamp(fma(-d2, k, T*k)), k = 2^(30 - e_T) chosen by the host.  Radii for
+    which it has no such constants (not finite; squared thresholds below 2^-90) must fall back to the compare-and-select form;
+    radii at the ends of the range it does cover (tiny, huge) and data scaled to sit right at them must give the oracle's bits."""
+    monkeypatch.setenv("NB_BOIDS_PC", pc)
+    rng = np.random.default_rng(7)
+    for scale, r1, r2, r3 in [(1e-20, 3e-40, 2e-20, 1e-19),      # r1 = 3e-40 is subnormal, (2e-20)^2 = 4e-40 too: no constants
+                              (1e-12, 2e-24, 1.5e-12, 1e-11),     # squared thresholds ~ 2^-78: inside the covered range
+                              (1e15, 2e30, 3e15, 5e15),           # huge: d2 ~ 1e30, k = 2^(30 - 100)
+                              (3e18, 3.0e38, 1.5e19, 1.8e19),     # d2 overflows to +inf for the far pairs: the test must fail for them
+                              (1.0, 1000.0, 5.0, float("inf"))]:  # an infinite radius: no constants
+        n = 700
+        pos = (rng.uniform(-1, 1, (n, 3)) * scale).astype(np.float32)
+        vel = (rng.uniform(-1, 1, (n, 3)) * scale).astype(np.float32)
+        bp, obp = nb.default_boids_params(), oracle.boids_params()
+        for k, val in (("rule_1_distance", r1), ("rule_2_distance", r2), ("rule_3_distance", r3)):
+            setattr(bp, k, val)
+            setattr(obp, k, val)
+        with nb.Scene(pos, vel) as sc:
+            sc.step_boids_n(2, bp)
+            p, v = sc.state()
+        p_ref, v_ref = oracle.boids_run(pos, vel, 2, obp)
+        nan = np.isnan(v_ref)
+        assert (np.isnan(v) == nan).all() and (bits(v)[~nan] == bits(v_ref)[~nan]).all(), f"scale={scale} r1={r1} r2={r2} r3={r3}"
+        nanp = np.isnan(p_ref)
+        assert (np.isnan(p) == nanp).all() and (bits(p)[~nanp] == bits(p_ref)[~nanp]).all(), f"scale={scale} (positions)"
+
+
 def _rule3_bound(t3):
     """the host's v_lim restated: largest binary32 V with ((2V)^2 + (2V)^2) + (2V)^2 <= t3, every operation in binary32"""
     def holds(b):
