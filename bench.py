@@ -68,6 +68,28 @@ def step_kernels(nb, mode, n, count):
     return nb._lib.planned_kernels(nb.default_params(mode=mode), n, count)
 
 
+def preheat(step, torch, dist, world, dev, ms):
+    """Untimed steps until the device holds its clock: after the idle gap in front of a leg (context creation, uploads) the part
+    ramps its clock over tens of milliseconds -- rocprofv3's trace of this bench shows the first launches of every leg 15-25 %
+    slow (profiles/r03/kernel_stats_all.csv: 6.7 -> 5.4 ms over the first six STRICT launches) -- which a warm-up counted in
+    steps (3 x 2.3 ms for FAST) does not cover.  The same number of steps on every rank (rank 0 decides).  Returns the count."""
+    if ms <= 0:
+        return 0
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    step()
+    step()
+    torch.cuda.synchronize(dev)
+    per = max((time.perf_counter() - t) / 2.0, 1e-5)
+    k = torch.tensor([min(2000, max(0, int(ms / 1e3 / per) - 1))], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(k, 0)
+    for _ in range(int(k.item())):
+        step()
+    torch.cuda.synchronize(dev)
+    return int(k.item()) + 2
+
+
 def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False):
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -84,6 +106,7 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     if world > 1:
         # untimed: bring the communicator and its channels up even when --warmup 0 (the target buffer is the scratch side)
         sc._all_gather_slots(sc.pos[sc.cur ^ 1])
+    pre = preheat(sc.step, torch, dist, world, dev, args.preheat_ms)
     for _ in range(warmup):
         sc.step()
     # kernel-only timing: events on the stream the kernel is launched on (torch's current stream)
@@ -112,7 +135,7 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     # (the overlapped form launches its two phases through step_phase: no per-kernel events there, wall time only)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count and timed_step.i == len(ev) else 0.0
-    return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps,
+    return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
             "kernels": step_kernels(nb, mode, sc.n, sc.count), "mode": "fast" if mode == nb.NB_MODE_FAST else "strict"}
 
 
@@ -124,6 +147,8 @@ def main():
     ap.add_argument("--n", type=int, default=131072, help="bodies (BASELINE: 131072)")
     ap.add_argument("--mode", choices=["strict", "fast"], default="strict",
                     help="arithmetic of the headline number: strict = bit-identical to the reference (default)")
+    ap.add_argument("--preheat-ms", type=float, default=250.0,
+                    help="untimed steps for this long in front of every leg's warm-up steps, until the clock ramp after the idle gap is over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs (other mode, 3-D data, boids)")
     ap.add_argument("--overlap-leg", action="store_true",
@@ -209,6 +234,9 @@ def main():
         "value": s["body_updates_per_s"],
         "unit": "body-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "preheat": {"ms": args.preheat_ms, "steps": res["preheat_steps"],
+                    "what": "untimed steps in front of the warm-up steps of every leg, until the clock ramp that follows an idle gap is over "
+                            "(--preheat-ms 0: none); the timed region is exactly `steps` steps"},
         "ms_per_step": s["ms_per_step"],
         "higher_is_better": True,
         "scaling": "strong",
@@ -289,6 +317,7 @@ def main():
         leg["name"] = "boids_controller"
         try:
             sc = nb.ShardedScene(pos, vel)
+            preheat(sc.step_boids, torch, dist, world, sc.device, args.preheat_ms)
             for _ in range(2):
                 sc.step_boids()
             torch.cuda.synchronize()

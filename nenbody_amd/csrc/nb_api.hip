@@ -44,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -85,6 +85,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->strict_bc = read_knob("NB_STRICT_BC");
     d->strict_sl = read_knob("NB_STRICT_SL");
     d->fast_sl = read_knob("NB_FAST_SL");
+    d->fast_pairs = read_knob("NB_FAST_PAIRS");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
     d->bc_prio = read_knob("NB_BC_PRIO");
     d->boids_pc = read_knob("NB_BOIDS_PC");
@@ -128,6 +129,7 @@ struct Plan {
     uint32_t pc;                            // STRICT: 0 = off, else producers per workgroup of the producer/consumer form (8 or 14)
     uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
     uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
+    uint32_t pairs;                         // FAST: 1 = pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n a multiple of 256; needs scratch
     uint32_t fsl;                           // FAST: 1 = scalar-load form (step_fast_sl_kernel, nb_nbody_sl.inc): whole-set launches, eight waves per workgroup; needs scratch
     uint32_t sl;                            // STRICT: 1 = scalar-load form (nb_nbody_sl.inc) instead of the LDS-tiled one-lane kernel; needs scratch
     uint32_t spin_budget;                   // block chain: polls per wait, 0 = kernel default (NB_BC_SPIN_BUDGET: the give-up test)
@@ -247,6 +249,11 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         pl.fsl = dbg.fast_sl.or_else((!pl.sym && pl.waves == 8u && n_total >= 4096u && p.tile == 0 && !dbg.tile.set && !dbg.fast_waves.set &&
                                       !dbg.fast_groups.set) ? 1u : 0u);
         if (pl.sym) pl.fsl = 0;
+        // The pairs form: whole sets (both bodies of a pair on this GPU), n a multiple of its 256-body blocks; its rows grow as
+        // n^2 / 2048 * 12 B, so it stops at 262 144 bodies (0.4 GB of scratch)
+        const bool pairs_ok = !pl.sym && count == n_total && n_total % 256u == 0 && n_total >= 4096u && n_total <= 262144u;
+        pl.pairs = (pairs_ok && dbg.fast_pairs.on()) ? 1u : 0u;
+        if (pl.pairs) pl.fsl = 0;
         if (pl.fsl) {  // its own split: 8 waves per workgroup, chunks of whole 256-record tiles (16-record requests stay aligned)
             uint32_t tile = 256u;
             pl.waves = 8u;
@@ -336,6 +343,7 @@ size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
     if (pl.bc || pl.sl) return nbk::strict_bc_scratch_bytes(pl.n_total);
     if (pl.sym) return (size_t)nbk::fast_sym_rows(pl.n_total, pl.ib, pl.sym) * count * sizeof(float4);
+    if (pl.pairs) return nbk::strict_bc_scratch_bytes(pl.n_total) + (size_t)3 * nbk::fast_pairs_rows(pl.n_total) * pl.n_total * sizeof(float);
     if (pl.fsl) return nbk::strict_bc_scratch_bytes(pl.n_total) + (pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
@@ -543,6 +551,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
                                               : pl.sym   ? (overrides().fast_sym_slp.on() ? nbk::launch_fast_sym_slp(a, pl.ib, pl.sym, stream) : nbk::launch_fast_sym(a, pl.ib, pl.sym, stream))
+                                              : pl.pairs ? nbk::launch_fast_pairs(a, scratch, stream)
                                               : pl.fsl   ? nbk::launch_fast_sl(a, pl.ib, pl.slices, scratch, stream)
                                               : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
                                                          : nbk::launch_fast(a, pl.tile, pl.ib, pl.groups, pl.slices, stream);
@@ -1745,6 +1754,7 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
                 a.stamps = stamps;
                 e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, c->scratch, c->stream)
                                                       : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, c->stream))
+                                             : pl.pairs ? nbk::launch_fast_pairs(a, c->scratch, c->stream)
                                              : pl.fsl ? nbk::launch_fast_sl(a, pl.ib, pl.slices, c->scratch, c->stream)
                                                       : nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, c->stream);
             }
@@ -2048,6 +2058,8 @@ NB_EXPORT int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t c
         k = pl.bc ? "step_strict_bc_kernel,planes_kernel" : pl.sl ? "step_strict_sl_kernel,planes_kernel" : pl.pc ? "step_strict_pc_kernel" : "step_strict_kernel";
     else if (pl.sym)
         k = "step_fast_sym_kernel,integrate_partials_kernel";
+    else if (pl.pairs)
+        k = "step_fast_pairs_kernel,planes_kernel,pairs_diag_kernel,pairs_integrate_kernel";
     else if (pl.fsl)
         k = std::string("step_fast_sl_kernel,planes_kernel") + (pl.slices > 1 ? ",integrate_partials_kernel" : "");
     else

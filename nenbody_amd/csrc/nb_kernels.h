@@ -79,6 +79,12 @@ hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint3
 hipError_t launch_fast_sl(const StepArgs &a, uint32_t ib, uint32_t slices, void *scratch, hipStream_t s);
 hipError_t launch_fast_sl_kernel(const StepArgs &a, uint32_t ib, uint32_t slices, const uint32_t *flags, uint32_t generation,
                                  const float *px, const float *py, const float *pz, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
+// FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n_total a multiple of 256; scratch = planes area
+// (strict_bc_scratch_bytes) followed by 3 x fast_pairs_rows() x n_total floats of rows
+hipError_t launch_fast_pairs(const StepArgs &a, void *scratch, hipStream_t s);
+hipError_t launch_fast_pairs_kernels(const StepArgs &a, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
+                                     const float *pz, float *rows, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
+uint32_t fast_pairs_rows(uint32_t n_total);
 // pair-symmetric fold of a whole set (n_total a multiple of 64 * ib); a.partial holds fast_sym_rows() rows of n_total records
 hipError_t launch_fast_sym(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);      // built without SLP packing
 hipError_t launch_fast_sym_slp(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);  // built with it (measurements)
