@@ -40,7 +40,16 @@ EXECUTED_OPS = {
     ("strict", "3d"): {"full_rate_ops": 26, "v_rcp_f32": 1.0},
     ("fast", "planar"): {"full_rate_ops": 7.5, "v_rcp_f32": 0.5, "note": "two pairs share one reciprocal: 3 extra multiplies per two pairs"},
     ("fast", "3d"): {"full_rate_ops": 10.5, "v_rcp_f32": 0.5},
+    # the pairs form (step_fast_pairs_kernel): every UNORDERED pair evaluated once and credited to both bodies; per ordered pair:
+    ("fast", "planar", "step_fast_pairs_kernel"): {"full_rate_ops": 5.25, "v_rcp_f32": 0.25,
+                                                   "note": "per ORDERED pair; one evaluation serves both bodies of a pair (18 v_pk_* + 2 v_mul + 4 v_sub "
+                                                           "+ 2 v_rcp per four unordered pairs), two evaluations share one reciprocal"},
+    ("fast", "3d", "step_fast_pairs_kernel"): {"full_rate_ops": 7.5, "v_rcp_f32": 0.25},
 }
+
+
+def executed_ops(mode, data, kernel):
+    return EXECUTED_OPS.get((mode, data, kernel), EXECUTED_OPS[(mode, data)])
 
 
 def committed_traffic(nb, kernels, n, count):
@@ -209,14 +218,16 @@ def main():
         traffic, source = committed_traffic(nb, r["kernels"], r["n"], r["count"])
         roof = {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                "frac_is": "nominal: the reference's 18 flop per ordered pair (flop_per_interaction) over the spec fp32 vector peak",
+                "frac_is": "nominal: the reference's 18 flop per ordered pair (flop_per_interaction) over the spec fp32 vector peak"
+                           + ("; the pairs form evaluates each unordered pair once for both bodies, so it executes about half of that "
+                              "nominal work and can pass 1.0" if r["kernels"][0] == "step_fast_pairs_kernel" else ""),
                 "bound_note": "fp32 vector ALU (SURVEY.md 8d): an all-pairs fp32 fold is neither HBM- nor MFMA-bound; see 'hbm'",
                 "traffic": traffic, "traffic_unit": "bytes/step (HBM, PMC)", "traffic_source": source,
                 "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
                 "kernel": r["kernels"][0], "kernels_per_step": r["kernels"],
                 "kernel_ms": r["kernel_ms"],
                 "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"],
-                "executed_per_interaction": EXECUTED_OPS[(r["mode"], data)]}
+                "executed_per_interaction": executed_ops(r["mode"], data, r["kernels"][0])}
         if traffic is not None and kernel_s > 0:  # how far from the HBM roofline the same launch is
             gbps = traffic / kernel_s / 1e9
             roof["hbm"] = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}

@@ -196,7 +196,7 @@ def load() -> ctypes.CDLL:
 # the sources that define the kernels bench.py times and profiles/hbm_traffic.json meters (the two whole-set folds, the block
 # chain the shards of a multi-GPU run take, their launchers): NOT the boids controller, the aux kernels, the producer/consumer
 # form, the host-side ABI or anything outside csrc/ -- edits there leave the PMC evidence valid
-BENCHED_KERNEL_SOURCES = ("nb_kernels.hip", "nb_kernels.h", "nb_launch.inc", "nb_nbody_strict.inc", "nb_nbody_sl.inc", "nb_nbody_fast.inc",
+BENCHED_KERNEL_SOURCES = ("nb_kernels.hip", "nb_kernels.h", "nb_launch.inc", "nb_nbody_strict.inc", "nb_nbody_sl.inc", "nb_nbody_sym.inc", "nb_nbody_fast.inc",
                           "nb_nbody_bc.inc")
 
 

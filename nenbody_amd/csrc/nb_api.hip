@@ -43,7 +43,7 @@ struct Knob {
     bool on() const { return set && v != 0; }
 };
 struct DebugOverrides {
-    Knob tile, fast_ib, fast_groups, fast_waves, fast_sym, fast_sym_slp, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
+    Knob tile, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
         strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
@@ -72,8 +72,6 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_ib = read_knob("NB_FAST_IB");
     d->fast_groups = read_knob("NB_FAST_GROUPS");
     d->fast_waves = read_knob("NB_FAST_WAVES");
-    d->fast_sym = read_knob("NB_FAST_SYM");
-    d->fast_sym_slp = read_knob("NB_FAST_SYM_SLP");
     d->fast_slices = read_knob("NB_FAST_SLICES");
     d->fast_no_share = read_knob("NB_FAST_NO_SHARE");
     d->strict_force_ieee = read_knob("NB_STRICT_FORCE_IEEE");
@@ -116,7 +114,6 @@ bool valid_tile(uint32_t t) { return t == 256 || t == 512 || t == 1024; }
 struct Plan {
     uint32_t tile;
     uint32_t ib;      // FAST: bodies per thread
-    uint32_t sym;     // FAST: 0 = ordered pairs; else the pair-symmetric fold with this many waves per workgroup (whole-set launches)
     uint32_t waves;   // FAST: 0 = workgroup-tile form; else the barrier-free form with this many waves per workgroup (= groups)
     uint32_t groups;  // FAST: 256-lane groups per workgroup, each folding its own j chunk (combined in LDS)
     uint32_t slices;  // FAST: blockIdx.y slices of the j range (combined through memory)
@@ -228,31 +225,20 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         pl.ib = fast_bodies_per_lane(n_total, count);
         pl.waves = fast_wave_form();
         fast_split(n_total, count, pl.ib, pl.waves, &pl.tile, &pl.groups, &pl.slices, &pl.j_chunk);
-        // The pair-symmetric fold (step_fast_sym_kernel) is OPT-IN (NB_FAST_SYM = waves per workgroup: 2, 4 or 8): it needs
-        // both bodies of a pair on this GPU (whole-set launches, n a multiple of 64 * ib), and its rows of partial sums --
-        // one per superblock, n^2 / (256 * waves) * 16 B in all: 268 MB at n = 131 072 with 4 waves -- make it 9-14 %
-        // faster than the ordered fold at the price of 30-60 times the algorithmic HBM traffic.
-        pl.sym = 0;
-        if (count == n_total && dbg.fast_sym.on()) {
-            const uint32_t sib = dbg.fast_ib.set && dbg.fast_ib.v == 2 ? 2u : 4u;
-            if (n_total % (64u * sib) == 0) {
-                pl.sym = (dbg.fast_sym.v == 2 || dbg.fast_sym.v == 4 || dbg.fast_sym.v == 8) ? dbg.fast_sym.v : 4u;
-                if (sib == 2 && pl.sym == 2) pl.sym = 4;
-                pl.ib = sib;
-            }
-        }
     }
     // FAST through scalar loads (nb_nbody_sl.inc) for sets of 4 096 bodies and more (below, its second launch -- the planes --
     // costs more than it saves): the same split of the j range over eight waves per workgroup and grid.y slices.  Naming a
     // tile, a wave count or groups asks for one of the LDS forms; NB_FAST_SL=0/1 decides outright.
     if (p.mode == NB_MODE_FAST) {
-        pl.fsl = dbg.fast_sl.or_else((!pl.sym && pl.waves == 8u && n_total >= 4096u && p.tile == 0 && !dbg.tile.set && !dbg.fast_waves.set &&
-                                      !dbg.fast_groups.set) ? 1u : 0u);
-        if (pl.sym) pl.fsl = 0;
-        // The pairs form: whole sets (both bodies of a pair on this GPU), n a multiple of its 256-body blocks; its rows grow as
-        // n^2 / 2048 * 12 B, so it stops at 262 144 bodies (0.4 GB of scratch)
-        const bool pairs_ok = !pl.sym && count == n_total && n_total % 256u == 0 && n_total >= 4096u && n_total <= 262144u;
-        pl.pairs = (pairs_ok && dbg.fast_pairs.on()) ? 1u : 0u;
+        const bool no_form_named = p.tile == 0 && !dbg.tile.set && !dbg.fast_waves.set && !dbg.fast_groups.set;
+        pl.fsl = dbg.fast_sl.or_else((pl.waves == 8u && n_total >= 4096u && no_form_named) ? 1u : 0u);
+        // The pairs form (nb_nbody_sym.inc): every UNORDERED pair once.  Whole sets only (both bodies of a pair on this GPU), n a
+        // multiple of its 256-body blocks.  It wants hundreds of superblock pairs -- one workgroup each, 2 048 bodies to a
+        // superblock -- so the plan takes it from 65 536 bodies on (496 workgroups), and its rows of partial sums grow as
+        // n^2 / 2048 * 12 B, so it stops at 262 144 (0.4 GB of scratch).  NB_FAST_PAIRS=0/1 decides outright where it can run.
+        const bool pairs_ok = count == n_total && n_total % 256u == 0 && n_total <= 262144u;
+        pl.pairs = (pairs_ok && dbg.fast_pairs.or_else((n_total >= 65536u && no_form_named && !dbg.fast_sl.set && !dbg.fast_ib.set &&
+                                                        !dbg.fast_slices.set) ? 1u : 0u)) ? 1u : 0u;
         if (pl.pairs) pl.fsl = 0;
         if (pl.fsl) {  // its own split: 8 waves per workgroup, chunks of whole 256-record tiles (16-record requests stay aligned)
             uint32_t tile = 256u;
@@ -342,7 +328,6 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
 size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
     if (pl.bc || pl.sl) return nbk::strict_bc_scratch_bytes(pl.n_total);
-    if (pl.sym) return (size_t)nbk::fast_sym_rows(pl.n_total, pl.ib, pl.sym) * count * sizeof(float4);
     if (pl.pairs) return nbk::strict_bc_scratch_bytes(pl.n_total) + (size_t)3 * nbk::fast_pairs_rows(pl.n_total) * pl.n_total * sizeof(float);
     if (pl.fsl) return nbk::strict_bc_scratch_bytes(pl.n_total) + (pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
@@ -550,7 +535,6 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
                                                  : pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, scratch, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
-                                              : pl.sym   ? (overrides().fast_sym_slp.on() ? nbk::launch_fast_sym_slp(a, pl.ib, pl.sym, stream) : nbk::launch_fast_sym(a, pl.ib, pl.sym, stream))
                                               : pl.pairs ? nbk::launch_fast_pairs(a, scratch, stream)
                                               : pl.fsl   ? nbk::launch_fast_sl(a, pl.ib, pl.slices, scratch, stream)
                                               : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
@@ -1701,8 +1685,8 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
     Plan pl;
     int rc = make_plan(p, n, n, &pl, &g_tls_error);
     if (rc != NB_OK) return rc;
-    if ((p.mode == NB_MODE_STRICT && (pl.bc || pl.pc || pl.lanes != 1)) || (p.mode == NB_MODE_FAST && (pl.sym || !pl.waves))) {
-        g_tls_error = "nb_diag_step_clock: only the whole-set kernels carry stamps (STRICT one lane per body, FAST wave form)";
+    if ((p.mode == NB_MODE_STRICT && (pl.bc || pl.pc || pl.lanes != 1)) || (p.mode == NB_MODE_FAST && !pl.waves && !pl.pairs)) {
+        g_tls_error = "nb_diag_step_clock: only the whole-set kernels carry stamps (STRICT one lane per body, FAST wave and pairs forms)";
         return NB_ERR_UNSUPPORTED;
     }
     nb_ctx *c = nullptr;
@@ -1712,7 +1696,11 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
     nb_init_state(1234, n, pos.data(), vel.data());
     rc = nb_upload(c, pos.data(), vel.data());
     const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl == 3u ? 64u : 256u) : 64u * pl.ib;
-    const size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
+    size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
+    if (p.mode == NB_MODE_FAST && pl.pairs) {  // one workgroup per superblock pair
+        const size_t ns = nbk::fast_pairs_rows(n);
+        groups = std::max<size_t>(1, ns * (ns - 1) / 2);
+    }
     unsigned long long *stamps = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipSuccess;
@@ -2056,8 +2044,6 @@ NB_EXPORT int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t c
     std::string k;
     if (p.mode == NB_MODE_STRICT)
         k = pl.bc ? "step_strict_bc_kernel,planes_kernel" : pl.sl ? "step_strict_sl_kernel,planes_kernel" : pl.pc ? "step_strict_pc_kernel" : "step_strict_kernel";
-    else if (pl.sym)
-        k = "step_fast_sym_kernel,integrate_partials_kernel";
     else if (pl.pairs)
         k = "step_fast_pairs_kernel,planes_kernel,pairs_diag_kernel,pairs_integrate_kernel";
     else if (pl.fsl)

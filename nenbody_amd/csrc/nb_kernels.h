@@ -85,10 +85,6 @@ hipError_t launch_fast_pairs(const StepArgs &a, void *scratch, hipStream_t s);
 hipError_t launch_fast_pairs_kernels(const StepArgs &a, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
                                      const float *pz, float *rows, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
 uint32_t fast_pairs_rows(uint32_t n_total);
-// pair-symmetric fold of a whole set (n_total a multiple of 64 * ib); a.partial holds fast_sym_rows() rows of n_total records
-hipError_t launch_fast_sym(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);      // built without SLP packing
-hipError_t launch_fast_sym_slp(const StepArgs &a, uint32_t ib, uint32_t waves, hipStream_t s);  // built with it (measurements)
-uint32_t fast_sym_rows(uint32_t n_total, uint32_t ib, uint32_t waves);
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);

@@ -34,7 +34,7 @@
 //   nb_nbody_bc.inc      STRICT block-chain kernel for small shards        (this unit)
 //   nb_nbody_sl.inc      STRICT scalar-load kernel: whole sets and large shards, no LDS, no barrier  (its own unit)
 //   nb_nbody_sym.inc     FAST pairs form: every unordered pair evaluated once, whole sets       (the scalar-load unit)
-//   nb_nbody_fast.inc    FAST kernels + fixed-order combine               (this unit; the pair-symmetric kernel: SLP-off unit)
+//   nb_nbody_fast.inc    FAST kernels + fixed-order combine               (this unit)
 //   nb_aux.inc           model matrices, cameras, random walk, self-test  (this unit)
 //   nb_boids.inc         boids controller, one-lane and producer/consumer (SLP-off unit)
 //   nb_launch.inc        host-side launchers
@@ -59,7 +59,6 @@ static constexpr int kWaves = kBlock / 64;
 #include "nb_nbody_sym.inc"   // FAST, every unordered pair once: hand-ordered like the scalar-load folds
 #elif defined(NBK_NOSLP_TU)
 #include "nb_boids.inc"
-#include "nb_nbody_fast.inc"  // for step_fast_sym_kernel only (its rotating sums are DPP operands: packed adds cannot take them)
 #else
 #include "nb_nbody_pc.inc"
 #include "nb_nbody_bc.inc"

@@ -290,7 +290,15 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     assert _lib.planned_kernels(nb.default_params(tile=1024), 131072, 131072) == ["step_strict_kernel"]
     assert _lib.planned_kernels(nb.default_params(), 131072, 16384) == ["step_strict_bc_kernel", "planes_kernel"]
     assert _lib.planned_kernels(nb.default_params(), 1000, 1000) == ["step_strict_kernel"]          # small sets: j-parallel
-    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_sl_kernel", "planes_kernel", "integrate_partials_kernel"]
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_pairs_kernel", "planes_kernel", "pairs_diag_kernel",
+                                                                                         "pairs_integrate_kernel"]
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 32768, 32768)[0] == "step_fast_sl_kernel"       # too few superblock pairs
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 1 << 20, 1 << 20)[0] == "step_fast_sl_kernel"     # rows of 6 GB: no
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072 + 64, 131072 + 64)[0] == "step_fast_sl_kernel"  # not whole blocks
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 65536)[0] == "step_fast_sl_kernel"      # a shard: the other body of a pair is elsewhere
+    # its scratch: planes + flags, then three planes of rows, one row per superblock of 2 048 bodies
+    fastp = nb.default_params(mode=nb.NB_MODE_FAST)
+    assert lib.nb_scratch_bytes(ctypes.byref(fastp), 131072, 131072) == (256 + 3 * 4 * 131072 + 64) + 3 * 64 * 131072 * 4
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST, tile=256), 131072, 131072) == ["step_fast_wave_kernel", "integrate_partials_kernel"]
     bad = ctypes.c_uint64()
     assert lib.nb_selftest_ladder(1 << 23, 1, ctypes.byref(bad), None) == _lib.NB_ERR_INVALID

@@ -745,18 +745,19 @@ def test_fast_scalar_load_form_every_launch_shape(nb, oracle, monkeypatch, ib, s
     assert_bits_equal(vs, vw, "FAST scalar-load form: shards == whole set (velocities)")
 
 
-@pytest.mark.parametrize("n,ib,sym", [(256, 4, 2), (1024, 4, 2), (2048, 4, 4), (4096, 4, 8), (2560, 4, 4), (6400, 4, 8), (1280, 2, 8), (640, 2, 4),
-                                      (32768, 4, 4)])
-def test_fast_pair_symmetric_fold(nb, oracle, monkeypatch, n, ib, sym):
-    """the pair-symmetric FAST fold (step_fast_sym_kernel): every unordered pair evaluated once and credited to both bodies --
-    the a-side in registers, the b-side in sums that rotate through the wave (DPP) and meet in LDS in a fixed order; diagonal
-    superblocks folded the ordered way.  Sizes with whole and partial superblocks (2560 = 10 blocks at 4 per superblock),
-    planar, 3-D and mixed tiles, coordinates too large for the shared reciprocal.  Opt-in (NB_FAST_SYM = waves per
-    workgroup); both builds of the kernel (with and without SLP packing).  Within FAST's tolerance of the oracle,
-    deterministic from run to run."""
-    monkeypatch.setenv("NB_FAST_SYM", str(sym))
-    monkeypatch.setenv("NB_FAST_IB", str(ib))
-    monkeypatch.setenv("NB_FAST_SYM_SLP", str(n // 256 % 2))
+@pytest.mark.parametrize("n", [256, 512, 2048, 2304, 4096, 6400, 8192, 32768])
+def test_fast_pairs_form(nb, oracle, monkeypatch, n):
+    """the FAST pairs form (step_fast_pairs_kernel, nb_nbody_sym.inc; what whole sets of 65 536 to 262 144 bodies run): every
+    unordered pair evaluated once and credited to both bodies -- the a-side in registers, the b-side in sums that rotate through
+    the wave (DPP) and meet in LDS in a fixed order; superblocks against themselves folded the ordered way
+    (pairs_diag_kernel); rows added in order (pairs_integrate_kernel).  Sizes with one superblock (256, 512, 2 048: no pairs
+    kernel at all), whole superblocks, and a last superblock of one block (2 304 = 9 blocks, 6 400 = 25); planar, 3-D and mixed
+    data, coordinates too large for the shared reciprocal.  Within FAST's tolerance of the oracle, deterministic from run to
+    run, and within that tolerance of the ordered fold."""
+    from nenbody_amd import _lib
+
+    monkeypatch.setenv("NB_FAST_PAIRS", "1")
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), n, n)[0] == "step_fast_pairs_kernel"
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
     for flavour in ("3d", "planar", "mixed", "big"):
         if n > 8192 and flavour != "planar":
@@ -793,7 +794,7 @@ def test_fast_pair_symmetric_fold(nb, oracle, monkeypatch, n, ib, sym):
         assert np.abs(v - v_ref).max() <= tol, f"{flavour}: {np.abs(v - v_ref).max():.3e} > {tol:.3e}"
         assert np.abs(p - p_ref).max() <= 4e-5 * acc + float(np.spacing(np.abs(p_ref).max())), flavour
     if n <= 8192:   # the same data through the ordered fold: the two must agree to FAST's tolerance
-        monkeypatch.setenv("NB_FAST_SYM", "0")
+        monkeypatch.setenv("NB_FAST_PAIRS", "0")
         with nb.Scene(pos, vel, fast) as sc:
             sc.step_n(k)
             p0, v0 = sc.state()

@@ -94,16 +94,20 @@ def test_boids_random_problems_bit_exact(nb, oracle, monkeypatch, case):
     assert (bits(got_v)[~nanv] == bits(ref_v)[~nanv]).all(), what
 
 
-@pytest.mark.parametrize("case", range(8))
+@pytest.mark.parametrize("case", range(12))
 def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
     rng = np.random.default_rng(3000 + case)
     n = int(rng.choice([64, 300, 1000, 2500, 4000]))
-    monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
-    monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
-    if case % 4 < 2:
-        monkeypatch.setenv("NB_FAST_GROUPS", str(int(rng.choice([1, 2, 4]))))    # an LDS form
+    if case >= 8:                                                                # the pairs form: whole 256-body blocks
+        n = 256 * int(rng.integers(1, 20))
+        monkeypatch.setenv("NB_FAST_PAIRS", "1")
     else:
-        monkeypatch.setenv("NB_FAST_SL", "1")                                    # the scalar-load form
+        monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
+        monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
+        if case % 4 < 2:
+            monkeypatch.setenv("NB_FAST_GROUPS", str(int(rng.choice([1, 2, 4]))))    # an LDS form
+        else:
+            monkeypatch.setenv("NB_FAST_SL", "1")                                    # the scalar-load form
     pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
     vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
     if case % 2 == 0:

@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nenbody_amd as nb
 def run(n, env, steps=1, z=False):
     for k in ("NB_FAST_SL","NB_FAST_PAIRS","NB_FORCE_3D"): os.environ.pop(k, None)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""FAST whole-set step, pairs form (NB_FAST_PAIRS=1) against the ordered scalar-load fold (NB_FAST_PAIRS=0), ms per step by size:
+where make_plan's lower bound for the pairs form comes from (profiles/r03/pairs_sizes.log).  Usage: pairs_sizes.py [N ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nenbody_amd as nb  # noqa: E402
+
+sizes = [int(x) for x in sys.argv[1:]] or [16384, 32768, 49152, 65536, 98304, 131072, 196608, 262144]
+for n in sizes:
+    pos, vel = nb.init_state(n, 1234)
+    row = []
+    for pairs in ("0", "1"):
+        os.environ["NB_FAST_PAIRS"] = pairs
+        nb.reload_env()
+        steps = max(10, min(400, int(3e11 / (float(n) * n))))
+        with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+            sc.step_n(max(steps, 20))
+            sc.sync()
+            best = 1e9
+            for _ in range(4):
+                t0 = time.perf_counter()
+                sc.step_n(steps)
+                sc.sync()
+                best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+        row.append(best)
+    print(f"N={n:7d}: ordered {row[0]:8.4f} ms   pairs {row[1]:8.4f} ms   ratio {row[1] / row[0]:.3f}", flush=True)
+os.environ.pop("NB_FAST_PAIRS", None)
+nb.reload_env()

@@ -181,8 +181,8 @@ def main():
         return fast_groups_sweep()
     if what == "fastsym":
         for n in (16384, 32768, 65536, 131072, 262144):
-            for env in ({"NB_FAST_SYM": 0}, {}, {"NB_FAST_SYM": 8}, {"NB_FAST_SYM": 4}, {"NB_FAST_SYM": 2}, {"NB_FAST_SYM": 8, "NB_FAST_IB": 2},
-                        {"NB_FAST_SYM": 8, "NB_FORCE_3D": 1}, {"NB_FAST_SYM": 0, "NB_FORCE_3D": 1}, {"NB_FAST_SYM": 0}, {}):
+            # the pairs form (every unordered pair once) against the ordered scalar-load fold
+            for env in ({"NB_FAST_PAIRS": 0}, {"NB_FAST_PAIRS": 1}, {"NB_FAST_PAIRS": 0, "NB_FORCE_3D": 1}, {"NB_FAST_PAIRS": 1, "NB_FORCE_3D": 1}):
                 run(n, nb.NB_MODE_FAST, max(5, min(200, int(2e12 / (float(n) * n)))), env)
         return
     if what == "lanes":
