@@ -79,12 +79,13 @@ hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint3
 hipError_t launch_fast_sl(const StepArgs &a, uint32_t ib, uint32_t slices, void *scratch, hipStream_t s);
 hipError_t launch_fast_sl_kernel(const StepArgs &a, uint32_t ib, uint32_t slices, const uint32_t *flags, uint32_t generation,
                                  const float *px, const float *py, const float *pz, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
-// FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n_total a multiple of 256; scratch = planes area
-// (strict_bc_scratch_bytes) followed by 3 x fast_pairs_rows() x n_total floats of rows
-hipError_t launch_fast_pairs(const StepArgs &a, void *scratch, hipStream_t s);
-hipError_t launch_fast_pairs_kernels(const StepArgs &a, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
+// FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n_total a multiple of 256; w = waves per workgroup
+// (8, 4, 2 or 1: superblocks of 256 w bodies); scratch = planes area (strict_bc_scratch_bytes) followed by 3 x fast_pairs_rows() x
+// n_total floats of rows
+hipError_t launch_fast_pairs(const StepArgs &a, uint32_t w, void *scratch, hipStream_t s);
+hipError_t launch_fast_pairs_kernels(const StepArgs &a, uint32_t w, const uint32_t *flags, uint32_t generation, const float *px, const float *py,
                                      const float *pz, float *rows, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
-uint32_t fast_pairs_rows(uint32_t n_total);
+uint32_t fast_pairs_rows(uint32_t n_total, uint32_t w);
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);

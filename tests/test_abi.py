@@ -292,7 +292,8 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     assert _lib.planned_kernels(nb.default_params(), 1000, 1000) == ["step_strict_kernel"]          # small sets: j-parallel
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072) == ["step_fast_pairs_kernel", "planes_kernel", "pairs_diag_kernel",
                                                                                          "pairs_integrate_kernel"]
-    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 32768, 32768)[0] == "step_fast_sl_kernel"       # too few superblock pairs
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 16384, 16384)[0] == "step_fast_sl_kernel"       # too few superblock pairs
+    assert lib.nb_scratch_bytes(ctypes.byref(nb.default_params(mode=nb.NB_MODE_FAST)), 65536, 65536) == (256 + 3 * 4 * 65536 + 64) + 3 * 64 * 65536 * 4  # superblocks of 1 024
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 1 << 20, 1 << 20)[0] == "step_fast_sl_kernel"     # rows of 6 GB: no
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072 + 64, 131072 + 64)[0] == "step_fast_sl_kernel"  # not whole blocks
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 65536)[0] == "step_fast_sl_kernel"      # a shard: the other body of a pair is elsewhere

@@ -745,18 +745,21 @@ def test_fast_scalar_load_form_every_launch_shape(nb, oracle, monkeypatch, ib, s
     assert_bits_equal(vs, vw, "FAST scalar-load form: shards == whole set (velocities)")
 
 
-@pytest.mark.parametrize("n", [256, 512, 2048, 2304, 4096, 6400, 8192, 32768])
-def test_fast_pairs_form(nb, oracle, monkeypatch, n):
+@pytest.mark.parametrize("n,w", [(256, 8), (512, 1), (512, 8), (2048, 2), (2304, 8), (2304, 4), (4096, 1), (4096, 8), (6400, 8), (6400, 2), (8192, 4),
+                                 (32768, 0)])
+def test_fast_pairs_form(nb, oracle, monkeypatch, n, w):
     """the FAST pairs form (step_fast_pairs_kernel, nb_nbody_sym.inc; what whole sets of 65 536 to 262 144 bodies run): every
     unordered pair evaluated once and credited to both bodies -- the a-side in registers, the b-side in sums that rotate through
     the wave (DPP) and meet in LDS in a fixed order; superblocks against themselves folded the ordered way
-    (pairs_diag_kernel); rows added in order (pairs_integrate_kernel).  Sizes with one superblock (256, 512, 2 048: no pairs
-    kernel at all), whole superblocks, and a last superblock of one block (2 304 = 9 blocks, 6 400 = 25); planar, 3-D and mixed
-    data, coordinates too large for the shared reciprocal.  Within FAST's tolerance of the oracle, deterministic from run to
-    run, and within that tolerance of the ordered fold."""
+    (pairs_diag_kernel); rows added in order (pairs_integrate_kernel).  Every workgroup width w (superblocks of 256 w bodies;
+    0 = the plan's own choice); sizes with one superblock (no pairs kernel at all), whole superblocks, and a last superblock of
+    one block (2 304 = 9 blocks, 6 400 = 25); planar, 3-D and mixed data, coordinates too large for the shared reciprocal.
+    Within FAST's tolerance of the oracle, deterministic from run to run, and within that tolerance of the ordered fold."""
     from nenbody_amd import _lib
 
     monkeypatch.setenv("NB_FAST_PAIRS", "1")
+    if w:
+        monkeypatch.setenv("NB_FAST_PAIRS_W", str(w))
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), n, n)[0] == "step_fast_pairs_kernel"
     fast = nb.default_params(mode=nb.NB_MODE_FAST)
     for flavour in ("3d", "planar", "mixed", "big"):

@@ -101,6 +101,7 @@ def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
     if case >= 8:                                                                # the pairs form: whole 256-body blocks
         n = 256 * int(rng.integers(1, 20))
         monkeypatch.setenv("NB_FAST_PAIRS", "1")
+        monkeypatch.setenv("NB_FAST_PAIRS_W", str(int(rng.choice([1, 2, 4, 8]))))
     else:
         monkeypatch.setenv("NB_FAST_IB", str(int(rng.choice([1, 2, 4]))))
         monkeypatch.setenv("NB_FAST_SLICES", str(int(rng.choice([1, 3, 8]))))
