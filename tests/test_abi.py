@@ -331,7 +331,10 @@ def test_committed_hbm_traffic_is_of_the_current_kernel_sources(nb):
     if t["src_sha"] != _lib.kernel_source_sha():
         pytest.skip("profiles/hbm_traffic.json is stale (kernel sources changed since the PMC passes): re-run tools/profile_bench.sh "
                     "and tools/pmc_summary.py --json")
-    for k in ("step_strict_sl_kernel", "step_fast_sl_kernel", "planes_kernel", "integrate_partials_kernel"):
+    # every kernel the two arithmetics launch per step at this shape, as the library plans it
+    planned = set(_lib.planned_kernels(nb.default_params(), 131072, 131072)) | set(_lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072))
+    assert planned >= {"step_strict_sl_kernel", "step_fast_pairs_kernel", "planes_kernel"}
+    for k in sorted(planned):
         assert t["kernels"][k]["bytes_per_launch"] == t["kernels"][k]["read"] + t["kernels"][k]["write"] > 0
 
 
