@@ -199,8 +199,9 @@ void nb_update_release(void);
  * float4 (x, y, z, 0) for positions and (vx, vy, vz, 0) for velocities.
  * `stream` is a hipStream_t (NULL = the default stream).  All launches are asynchronous.                 */
 
-/* Bytes of device scratch nb_launch_step needs for this shape (may be 0): FAST with a split j range keeps partial sums
- * there, STRICT below 65 536 bodies per rank the x / y / z planes of the position set (12 B per body of the WHOLE set). */
+/* Bytes of device scratch nb_launch_step needs for this shape (may be 0): the scalar-load kernels keep x / y / z planes of the
+ * position set there (12 B per body of the WHOLE set), FAST its rows of partial sums as well (a whole set in the pairs form:
+ * n_total x n_total / 2048 x 12 B -- 100 MB at 131 072 bodies).  Always ask; the number changes with shape and mode. */
 size_t nb_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t count);
 
 /* One step for bodies [first, first+count) of a set of n_total:
