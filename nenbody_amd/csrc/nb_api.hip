@@ -293,8 +293,12 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     // below 65 536 bodies give each body S lanes until the shard supplies 2 waves per SIMD (256 CUs x 4 SIMDs x 2 =
     // 2048 waves).  The DPP adds of the j-parallel form cost about twice a plain add, so S = 1 stays ahead down to
     // one wave per SIMD (measured: profiles/r01_jp/sweep_lanes.log).
+    // (Round 3: the line is 57 344 bodies, not 65 536 -- above it the scalar-load kernel, one wave per SIMD and nothing to wait
+    // for, beats every chained form: a 65 536-body shard of 131 072 takes 2.95 ms against the block chain's 3.35,
+    // profiles/r03/shard_strict_forms.log; the block chain costs 0.84 ms per 16 384 bodies, so the two meet at 57 500.)
+    constexpr uint32_t kChainMax = 57344u;
     pl.lanes = 1;
-    if (count < 65536u)
+    if (count <= kChainMax)
         while (pl.lanes < 16 && (uint64_t)count * pl.lanes < 2048ull * 64ull) pl.lanes *= 2;
     pl.lanes = dbg.strict_lanes.or_else(pl.lanes);
     if (pl.lanes != 1 && pl.lanes != 2 && pl.lanes != 4 && pl.lanes != 8 && pl.lanes != 16) pl.lanes = 1;
@@ -304,7 +308,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     if (pl.lanes == 16) pl.unroll = 2;
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 512) pl.tile = 1024;  // built j-parallel shapes: 256, 1024
     if (p.mode == NB_MODE_STRICT && pl.lanes > 1 && pl.tile == 1024 && pl.unroll == 2 && pl.lanes < 8) pl.unroll = 4;
-    // Shards of up to 65 536 bodies cannot fill the chip with one lane per body (the running sum is a serial chain per
+    // Shards of up to 57 344 bodies (round 1-2: 65 536) cannot fill the chip with one lane per body (the running sum is a serial chain per
     // body).  Default there: the block-chain form (nb_nbody_bc.inc).  Against all 131 072 bodies: 16 384 bodies 0.85 ms
     // (producer/consumer, 14 producers + 2 consumers per 64 bodies: 1.15; j-parallel S = 8: 2.1), 32 768: 1.67 (2.28),
     // 65 536: 3.30 (one lane per body 3.52); the whole set: 6.57 against 6.19 for one lane per body, which therefore keeps
@@ -315,15 +319,15 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
     // the form gains), from there on the block chain (round 1's four launches had put that line at 4 096).
     // Naming another shape (NB_STRICT_PC / NB_STRICT_LANES) turns the block chain off; NB_STRICT_BC=0/1 decides outright.
     constexpr uint32_t kSmallSet = 1536u;
-    pl.pc = dbg.strict_pc.or_else((count < 65536u && n_total >= kSmallSet) ? 14u : 0u);
+    pl.pc = dbg.strict_pc.or_else((count <= kChainMax && n_total >= kSmallSet) ? 14u : 0u);
     if (pl.pc == 1) pl.pc = 8;
     if (pl.pc != 0 && pl.pc != 8 && pl.pc != 14) pl.pc = 8;
     pl.n_total = n_total;
-    pl.bc = dbg.strict_bc.or_else((count <= 65536u && n_total >= kSmallSet && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
+    pl.bc = dbg.strict_bc.or_else((count <= kChainMax && n_total >= kSmallSet && !dbg.strict_pc.set && !dbg.strict_lanes.set) ? 1u : 0u);
     pl.bc = (pl.bc && p.mode == NB_MODE_STRICT) ? 1u : 0u;
     pl.spin_budget = dbg.bc_spin_budget.or_else(0u);
     pl.bc_prio = dbg.bc_prio.or_else(1u) ? 1u : 0u;
-    // Above the block chain's range (whole sets, shards of more than 65 536 bodies) one lane per body fills the chip, and the
+    // Above the block chain's range (whole sets, shards of more than 57 344 bodies) one lane per body fills the chip, and the
     // records reach the lanes through scalar loads instead of LDS tiles: no barrier, no ds_read (nb_nbody_sl.inc).  Naming a
     // tile (params.tile / NB_TILE), a lane count or the producer/consumer form asks for the LDS-tiled kernel; NB_STRICT_SL=0/1 decides outright.
     pl.sl = dbg.strict_sl.or_else((!pl.bc && !pl.pc && pl.lanes == 1 && p.tile == 0 && !dbg.tile.set && !dbg.strict_lanes.set &&

@@ -748,7 +748,7 @@ def test_fast_scalar_load_form_every_launch_shape(nb, oracle, monkeypatch, ib, s
 @pytest.mark.parametrize("n,w", [(256, 8), (512, 1), (512, 8), (2048, 2), (2304, 8), (2304, 4), (4096, 1), (4096, 8), (6400, 8), (6400, 2), (8192, 4),
                                  (32768, 0)])
 def test_fast_pairs_form(nb, oracle, monkeypatch, n, w):
-    """the FAST pairs form (step_fast_pairs_kernel, nb_nbody_sym.inc; what whole sets of 65 536 to 262 144 bodies run): every
+    """the FAST pairs form (step_fast_pairs_kernel, nb_nbody_sym.inc; what whole sets of 32 768 to 262 144 bodies run): every
     unordered pair evaluated once and credited to both bodies -- the a-side in registers, the b-side in sums that rotate through
     the wave (DPP) and meet in LDS in a fixed order; superblocks against themselves folded the ordered way
     (pairs_diag_kernel); rows added in order (pairs_integrate_kernel).  Every workgroup width w (superblocks of 256 w bodies;
