@@ -255,6 +255,13 @@ def test_plan_arithmetic_over_many_shapes(nb):
                     elif mode == nb.NB_MODE_FAST:
                         planes = 256 + 3 * 4 * ((n + 63) // 64 * 64) + 64     # the scalar-load form (sets of 4 096 bodies and more, library's own tile)
                         rows = b - planes if (tile == 0 and n >= 4096) else b
+                        if tile == 0 and count == n and n % 256 == 0 and 32768 <= n <= 4194304:   # the pairs form
+                            w = 8 if n >= 131072 else 4
+                            if n <= 262144:      # one tile: three planes of rows, one row per superblock
+                                assert rows == 3 * (n // (256 * w)) * n * 4
+                            else:                # chunks of 131 072: running sums + the rows of an a side and a b side
+                                assert rows == 3 * n * 4 + 2 * 3 * 64 * 131072 * 4
+                            continue
                         assert rows >= 0 and rows % (count * 16) == 0 and rows // (count * 16) <= 64
                     else:
                         assert b in (0, 256 + 3 * 4 * ((n + 63) // 64 * 64) + 64)
@@ -294,7 +301,7 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
                                                                                          "pairs_integrate_kernel"]
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 16384, 16384)[0] == "step_fast_sl_kernel"       # too few superblock pairs
     assert lib.nb_scratch_bytes(ctypes.byref(nb.default_params(mode=nb.NB_MODE_FAST)), 65536, 65536) == (256 + 3 * 4 * 65536 + 64) + 3 * 64 * 65536 * 4  # superblocks of 1 024
-    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 1 << 20, 1 << 20)[0] == "step_fast_sl_kernel"     # rows of 6 GB: no
+    assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 1 << 20, 1 << 20)[0] == "step_fast_pairs_kernel"  # in chunks of 131 072
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072 + 64, 131072 + 64)[0] == "step_fast_sl_kernel"  # not whole blocks
     assert _lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 65536)[0] == "step_fast_sl_kernel"      # a shard: the other body of a pair is elsewhere
     # its scratch: planes + flags, then three planes of rows, one row per superblock of 2 048 bodies
