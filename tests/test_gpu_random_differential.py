@@ -122,3 +122,32 @@ def test_fast_random_problems_within_tolerance(nb, oracle, monkeypatch, case):
     # relative force error per step, plus one ulp of the velocity itself (v + a*dt is rounded after the sum)
     assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n}"
     assert np.abs(got_p - ref_p).max() <= 1e-5, f"case {case}"
+
+
+@pytest.mark.parametrize("case", range(max(8, CASES // 3)))
+def test_fast_pairs_form_random_problems(nb, oracle, monkeypatch, case):
+    """the FAST pairs form over random block counts, workgroup widths and chunkings (one tile, several, a ragged last chunk),
+    planar and 3-D: within FAST's tolerance of the oracle and bit-identical from run to run"""
+    rng = np.random.default_rng(7000 + case)
+    w = int(rng.choice([1, 2, 4, 8]))
+    n = 256 * int(rng.integers(1, 28))
+    monkeypatch.setenv("NB_FAST_PAIRS", "1")
+    monkeypatch.setenv("NB_FAST_PAIRS_W", str(w))
+    if case % 3:
+        monkeypatch.setenv("NB_FAST_PAIRS_CHUNK", str(256 * w * int(rng.integers(1, 5))))
+    pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
+    vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
+    if case % 2 == 0:
+        pos[:, 2] = 0
+        vel[:, 2] = 0
+    outs = []
+    for _ in range(2):
+        with nb.Scene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST)) as sc:
+            sc.step_n(1)
+            outs.append(sc.state())
+    assert (bits(outs[0][0]) == bits(outs[1][0])).all() and (bits(outs[0][1]) == bits(outs[1][1])).all(), f"case {case}: not deterministic"
+    got_p, got_v = outs[0]
+    ref_p, ref_v = oracle.run(pos, vel, 1)
+    acc = np.abs(ref_v - vel).max()
+    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n} w={w}"
+    assert np.abs(got_p - ref_p).max() <= 1e-5, f"case {case}"
