@@ -84,18 +84,23 @@ def preheat(step, torch, dist, world, dev, ms):
     steps (3 x 2.3 ms for FAST) does not cover.  The same number of steps on every rank (rank 0 decides).  Returns the count."""
     if ms <= 0:
         return 0
-    torch.cuda.synchronize(dev)
+
+    def sync():
+        if getattr(dev, "type", "cuda") == "cuda":   # (a CPU device: the gloo test of this function)
+            torch.cuda.synchronize(dev)
+
+    sync()
     t = time.perf_counter()
     step()
     step()
-    torch.cuda.synchronize(dev)
+    sync()
     per = max((time.perf_counter() - t) / 2.0, 1e-5)
     k = torch.tensor([min(2000, max(0, int(ms / 1e3 / per) - 1))], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.broadcast(k, 0)
+        dist.broadcast(k, 0)   # every step holds a collective: ranks that disagreed on the count would hang in it
     for _ in range(int(k.item())):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     return int(k.item()) + 2
 
 

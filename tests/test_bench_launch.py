@@ -46,3 +46,48 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     assert "REHEARSAL" in line["data"]
     assert line["scaling"] == "strong" and line["value"] > 0
     assert "sharding" in line["config"] and "x2" in line["config"]["sharding"]
+
+
+def _preheat_rank(rank, world, port, out_dir):
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def step():   # as a real step: some work of rank-dependent length, then a collective
+        time.sleep(0.002 * (1 + 3 * rank))
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        calls.append(float(t.item()))
+
+    count = bench.preheat(step, torch, dist, world, torch.device("cpu"), 60.0)
+    dist.barrier()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"count": count, "calls": len(calls), "sums": sorted(set(calls))}, f)
+    dist.destroy_process_group()
+
+
+def test_preheat_runs_the_same_number_of_steps_on_every_rank(tmp_path):
+    """bench.py's preheat steps for a wall-clock span, and every step holds a collective: ranks that timed their own steps and
+    chose their own counts would leave one of them waiting in an all-gather forever.  Rank 0 decides; here three gloo ranks
+    whose steps take 2, 8 and 14 ms."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    world = 3
+    mp.spawn(_preheat_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert len({g["count"] for g in got}) == 1 and got[0]["count"] >= 3          # one count, more than the two timed steps
+    assert all(g["calls"] == g["count"] for g in got)
+    assert all(g["sums"] == [float(world)] for g in got)                          # every collective met all ranks
