@@ -1869,6 +1869,7 @@ struct PhasePlan {
     Plan base;                 // tile, ib, the sharing verdict, force_3d ...
     uint32_t len[2];           // records folded by phase 0 (the range) and phase 1 (the rest)
     uint32_t groups[2], slices[2], chunk[2];
+    uint32_t fsl;              // 1 = the phases fold through scalar loads (step_fast_sl_kernel; the planes area in front of the rows), 0 = LDS forms
 };
 
 int make_phase_plan(const nb_params &p, uint32_t n_total, uint32_t count, uint32_t j_lo, uint32_t j_hi, PhasePlan *out, std::string *err)
@@ -1885,11 +1886,18 @@ int make_phase_plan(const nb_params &p, uint32_t n_total, uint32_t count, uint32
     if (rc != NB_OK) return rc;
     out->len[0] = j_hi - j_lo;
     out->len[1] = n_total - out->len[0];
+    // Through scalar loads where a shard's one-call step would go that way (the plan's own choice, never the pairs form: a phase
+    // folds a range of j's, not pairs): eight waves per workgroup, chunks of whole 256-record tiles; else the LDS forms.
+    out->fsl = (out->base.fsl || out->base.pairs) ? 1u : 0u;
     for (int ph = 0; ph < 2; ++ph) {
-        uint32_t tile = out->base.tile;
-        fast_split(out->len[ph], count, out->base.ib, out->base.waves, &tile, &out->groups[ph], &out->slices[ph], &out->chunk[ph]);
+        uint32_t tile = out->fsl ? 256u : out->base.tile;
+        fast_split(out->len[ph], count, out->base.ib, out->fsl ? 8u : out->base.waves, &tile, &out->groups[ph], &out->slices[ph], &out->chunk[ph]);
     }
     return NB_OK;
+}
+size_t phase_scratch_bytes(const PhasePlan &pp, uint32_t count)
+{
+    return (pp.fsl ? nbk::strict_bc_scratch_bytes(pp.base.n_total) : 0) + (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4);
 }
 }  // namespace
 
@@ -1944,7 +1952,7 @@ NB_EXPORT size_t nb_scratch_bytes_phased(const nb_params *params, uint32_t n_tot
     PhasePlan pp;
     std::string err;
     if (make_phase_plan(p, n_total, count, j_lo, j_hi, &pp, &err) != NB_OK) return 0;
-    return (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4);
+    return phase_scratch_bytes(pp, count);
 }
 
 namespace {
@@ -1957,7 +1965,8 @@ int launch_phase_planned(const nb_params &p, const PhasePlan &pp, uint32_t n_tot
     a.pos_in = (const float4 *)pos_in;
     a.pos_out = (float4 *)pos_out;
     a.vel = (float4 *)vel;
-    a.partial = (float4 *)scratch;
+    char *const rows = (char *)scratch + (pp.fsl ? nbk::strict_bc_scratch_bytes(n_total) : 0);  // the partial rows: behind the planes area
+    a.partial = (float4 *)rows;
     a.n_total = n_total;
     a.first = first;
     a.count = count;
@@ -1976,10 +1985,11 @@ int launch_phase_planned(const nb_params &p, const PhasePlan &pp, uint32_t n_tot
         a.j_chunk = pp.chunk[0];
         a.partial_row0 = 0;
         if (pp.len[0])
-            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[0], stream)
-                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[0], pp.slices[0], stream);
+            e = pp.fsl   ? nbk::launch_fast_sl_phase(a, pl.ib, pp.slices[0], true, j_lo, j_lo + pp.len[0], scratch, stream)
+                : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[0], stream)
+                           : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[0], pp.slices[0], stream);
         else
-            e = hipMemsetAsync(scratch, 0, (size_t)pp.slices[0] * count * sizeof(float4), stream);
+            e = hipMemsetAsync(rows, 0, (size_t)pp.slices[0] * count * sizeof(float4), stream);
     } else {  // the set without that range -> rows [slices[0], slices[0] + slices[1]), then every row in order + integrate
         a.j_count = pp.len[1];
         a.j_base = 0;
@@ -1988,11 +1998,11 @@ int launch_phase_planned(const nb_params &p, const PhasePlan &pp, uint32_t n_tot
         a.j_chunk = pp.chunk[1];
         a.partial_row0 = pp.slices[0];
         if (pp.len[1])
-            e = pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[1], stream)
-                         : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[1], pp.slices[1], stream);
+            e = pp.fsl   ? nbk::launch_fast_sl_phase(a, pl.ib, pp.slices[1], false, 0, 0, scratch, stream)
+                : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pp.slices[1], stream)
+                           : nbk::launch_fast(a, pl.tile, pl.ib, pp.groups[1], pp.slices[1], stream);
         else
-            e = hipMemsetAsync((char *)scratch + (size_t)pp.slices[0] * count * sizeof(float4), 0,
-                               (size_t)pp.slices[1] * count * sizeof(float4), stream);
+            e = hipMemsetAsync(rows + (size_t)pp.slices[0] * count * sizeof(float4), 0, (size_t)pp.slices[1] * count * sizeof(float4), stream);
         if (e == hipSuccess) e = nbk::launch_integrate_partials(a, pp.slices[0] + pp.slices[1], stream);
     }
     if (e != hipSuccess) {
@@ -2025,7 +2035,7 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
     int rc = cached_phase_plan(p, n_total, count, j_lo, j_hi, &ppp, &g_tls_error);
     if (rc != NB_OK) return rc;
     const PhasePlan &pp = *ppp;
-    if (scratch_bytes < (size_t)(pp.slices[0] + pp.slices[1]) * count * sizeof(float4)) {
+    if (scratch_bytes < phase_scratch_bytes(pp, count)) {
         g_tls_error = "nb_launch_step_phase: scratch smaller than nb_scratch_bytes_phased()";
         return NB_ERR_INVALID;
     }

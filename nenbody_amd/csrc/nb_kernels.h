@@ -77,6 +77,8 @@ hipError_t launch_fast_wave(const StepArgs &a, uint32_t tile, uint32_t ib, uint3
 // FAST through scalar loads (nb_nbody_sl.inc): whole-set j range, eight waves per workgroup x slices; scratch = planes area
 // (strict_bc_scratch_bytes) followed by the slices' partial rows
 hipError_t launch_fast_sl(const StepArgs &a, uint32_t ib, uint32_t slices, void *scratch, hipStream_t s);
+hipError_t launch_fast_sl_phase(const StepArgs &a, uint32_t ib, uint32_t slices, bool range, uint32_t r0, uint32_t r1, void *scratch,
+                                hipStream_t s);  // one phase of a step in two phases (nb_launch_step_phase); rows behind the planes area
 hipError_t launch_fast_sl_kernel(const StepArgs &a, uint32_t ib, uint32_t slices, const uint32_t *flags, uint32_t generation,
                                  const float *px, const float *py, const float *pz, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
 // FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n_total a multiple of 256; w = waves per workgroup
