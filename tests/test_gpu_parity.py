@@ -275,6 +275,25 @@ def test_headline_size_fast_drift_curve(nb, capsys):
     assert d[10][2] < 1e-4, curve           # the typical body is inside the north_star's bound through the free fall
 
 
+def test_headline_size_fast_is_deterministic_and_finite_through_the_collapse(nb):
+    """FAST at the headline size (the pairs form: 2 016 workgroups whose b-side sums meet in LDS, rows added in index order):
+    two runs of 100 steps give the same bits after every tenth step -- no sum depends on which workgroup finished first --, and
+    no body goes non-finite while the cloud collapses and rebounds (step ~40)."""
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    from nenbody_amd import _lib
+    assert _lib.planned_kernels(fast, n, n)[0] == "step_fast_pairs_kernel"
+    with nb.Scene(pos, vel, fast) as a, nb.Scene(pos, vel, fast) as b:
+        for k in range(10):
+            a.step_n(10)
+            b.step_n(10)
+            (pa, va), (pb, vb) = a.state(), b.state()
+            assert_bits_equal(pa, pb, f"step {10 * (k + 1)}: positions differ between two runs")
+            assert_bits_equal(va, vb, f"step {10 * (k + 1)}: velocities differ between two runs")
+            assert np.isfinite(pa).all() and np.isfinite(va).all(), f"step {10 * (k + 1)}"
+
+
 def test_strict_ieee_fallback_path_bit_exact(nb, oracle, lanes, monkeypatch):
     """The guarded '/' path (taken when coordinates leave the range where the shared-reciprocal ladder is
     proven exact) must give the same bits; force it for every tile."""
