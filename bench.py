@@ -41,10 +41,10 @@ EXECUTED_OPS = {
     ("fast", "planar"): {"full_rate_ops": 7.5, "v_rcp_f32": 0.5, "note": "two pairs share one reciprocal: 3 extra multiplies per two pairs"},
     ("fast", "3d"): {"full_rate_ops": 10.5, "v_rcp_f32": 0.5},
     # the pairs form (step_fast_pairs_kernel): every UNORDERED pair evaluated once and credited to both bodies; per ordered pair:
-    ("fast", "planar", "step_fast_pairs_kernel"): {"full_rate_ops": 5.25, "v_rcp_f32": 0.25,
-                                                   "note": "per ORDERED pair; one evaluation serves both bodies of a pair (18 v_pk_* + 2 v_mul + 4 v_sub "
-                                                           "+ 2 v_rcp per four unordered pairs), two evaluations share one reciprocal"},
-    ("fast", "3d", "step_fast_pairs_kernel"): {"full_rate_ops": 7.5, "v_rcp_f32": 0.25},
+    ("fast", "planar", "step_fast_pairs_kernel"): {"full_rate_ops": 5.0, "v_rcp_f32": 0.25,
+                                                   "note": "per ORDERED pair; one evaluation serves both bodies of a pair (36 v_pk_* + 4 v_mul + 4 v_sub "
+                                                           "+ 4 v_rcp per eight unordered pairs of a lane's eight bodies), two evaluations share one reciprocal"},
+    ("fast", "3d", "step_fast_pairs_kernel"): {"full_rate_ops": 7.125, "v_rcp_f32": 0.25},
 }
 
 

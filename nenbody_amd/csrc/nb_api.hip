@@ -43,7 +43,7 @@ struct Knob {
     bool on() const { return set && v != 0; }
 };
 struct DebugOverrides {
-    Knob tile, fast_pairs_w, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
+    Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
         strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
@@ -86,6 +86,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_pairs = read_knob("NB_FAST_PAIRS");
     d->fast_pairs_w = read_knob("NB_FAST_PAIRS_W");
     d->fast_pairs_chunk = read_knob("NB_FAST_PAIRS_CHUNK");
+    d->fast_pairs_np = read_knob("NB_FAST_PAIRS_NP");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
     d->bc_prio = read_knob("NB_BC_PRIO");
     d->boids_pc = read_knob("NB_BOIDS_PC");
@@ -129,6 +130,7 @@ struct Plan {
     uint32_t no_packed;                     // STRICT, one lane per body: 1 = do not use the j-packed planar fold (NB_STRICT_NO_PACKED=1)
     uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
     uint32_t pairs;                         // FAST: the pairs form (nb_nbody_sym.inc: every unordered pair once; whole sets, n a multiple of 256; needs scratch) with this many waves per workgroup (8, 4, 2, 1); 0 = another form
+    uint32_t pairs_np;                      // pairs form: packed pairs of bodies per lane, 2 or 4 (blocks of 256 or 512 bodies)
     uint32_t pairs_chunk;                   // pairs form: bodies per chunk of the two-level walk (0: the default -- one tile up to 262 144 bodies, chunks of 131 072 beyond)
     uint32_t fsl;                           // FAST: 1 = scalar-load form (step_fast_sl_kernel, nb_nbody_sl.inc): whole-set launches, eight waves per workgroup; needs scratch
     uint32_t sl;                            // STRICT: 1 = scalar-load form (nb_nbody_sl.inc) instead of the LDS-tiled one-lane kernel; needs scratch
@@ -246,14 +248,23 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         // NB_FAST_PAIRS=0/1 decides outright where it can run, NB_FAST_PAIRS_W names W (8, 4, 2, 1), NB_FAST_PAIRS_CHUNK the chunk.
         constexpr uint32_t kPairsMinN = 32768u;
         const bool pairs_ok = count == n_total && n_total % 256u == 0 && n_total <= 4194304u;
-        uint32_t pw = n_total >= 131072u ? 8u : 4u;
-        if (dbg.fast_pairs_w.set && (dbg.fast_pairs_w.v == 1 || dbg.fast_pairs_w.v == 2 || dbg.fast_pairs_w.v == 4 || dbg.fast_pairs_w.v == 8))
+        // From 98 304 bodies on a lane holds EIGHT bodies (four packed pairs, blocks of 512) where the size allows: the step's fixed
+        // costs -- the rotating sums' four instructions, the LDS read, the hazard nops -- are shared by twice the pairs: 1.68 against
+        // 1.78 ms at 131 072 (W = 4), 6.61 against 7.19 at 262 144, 106 against 114 at 2^20 (profiles/r03/pairs_sizes_np.log); below,
+        // four bodies per lane (142 registers leave three waves per SIMD, too few where the workgroups are few as well).
+        uint32_t pnp = (n_total >= 98304u && n_total % 512u == 0) ? 4u : 2u;
+        if (dbg.fast_pairs_np.set && (dbg.fast_pairs_np.v == 2 || (dbg.fast_pairs_np.v == 4 && n_total % 512u == 0))) pnp = dbg.fast_pairs_np.v;
+        uint32_t pw = pnp == 4u ? (n_total >= 131072u ? 4u : 2u) : (n_total >= 131072u ? 8u : 4u);
+        if (dbg.fast_pairs_w.set && (dbg.fast_pairs_w.v == 1 || dbg.fast_pairs_w.v == 2 || dbg.fast_pairs_w.v == 4 || (dbg.fast_pairs_w.v == 8 && pnp == 2u)))
             pw = dbg.fast_pairs_w.v;
         pl.pairs = (pairs_ok && dbg.fast_pairs.or_else((n_total >= kPairsMinN && no_form_named && !dbg.fast_sl.set && !dbg.fast_ib.set &&
                                                         !dbg.fast_slices.set) ? 1u : 0u)) ? pw : 0u;
+        pl.pairs_np = pnp;
         pl.pairs_chunk = 0;
-        if (pl.pairs && dbg.fast_pairs_chunk.on())  // whole superblocks per chunk
-            pl.pairs_chunk = std::max(256u * pw, dbg.fast_pairs_chunk.v / (256u * pw) * (256u * pw));
+        if (pl.pairs && dbg.fast_pairs_chunk.on()) {  // whole superblocks per chunk
+            const uint32_t super = 128u * pnp * pw;
+            pl.pairs_chunk = std::max(super, dbg.fast_pairs_chunk.v / super * super);
+        }
         if (pl.pairs) pl.fsl = 0;
         if (pl.fsl) {  // its own split: 8 waves per workgroup, chunks of whole 256-record tiles (16-record requests stay aligned)
             uint32_t tile = 256u;
@@ -347,7 +358,7 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
 size_t plan_scratch_bytes(const Plan &pl, uint32_t count)
 {
     if (pl.bc || pl.sl) return nbk::strict_bc_scratch_bytes(pl.n_total);
-    if (pl.pairs) return nbk::strict_bc_scratch_bytes(pl.n_total) + nbk::fast_pairs_scratch_floats(pl.n_total, pl.pairs, pl.pairs_chunk) * sizeof(float);
+    if (pl.pairs) return nbk::strict_bc_scratch_bytes(pl.n_total) + nbk::fast_pairs_scratch_floats(pl.n_total, pl.pairs, pl.pairs_np, pl.pairs_chunk) * sizeof(float);
     if (pl.fsl) return nbk::strict_bc_scratch_bytes(pl.n_total) + (pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0);
     return pl.slices > 1 ? (size_t)pl.slices * count * sizeof(float4) : 0;
 }
@@ -554,7 +565,7 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
                                                  : pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, scratch, stream)
                                                  : pl.pc ? nbk::launch_strict_pc(a, pl.pc, stream)
                                                        : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, stream))
-                                              : pl.pairs ? nbk::launch_fast_pairs(a, pl.pairs, pl.pairs_chunk, scratch, stream)
+                                              : pl.pairs ? nbk::launch_fast_pairs(a, pl.pairs, pl.pairs_np, pl.pairs_chunk, scratch, stream)
                                               : pl.fsl   ? nbk::launch_fast_sl(a, pl.ib, pl.slices, scratch, stream)
                                               : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
                                                          : nbk::launch_fast(a, pl.tile, pl.ib, pl.groups, pl.slices, stream);
@@ -1717,7 +1728,7 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
     const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl == 3u ? 64u : 256u) : 64u * pl.ib;
     size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
     if (p.mode == NB_MODE_FAST && pl.pairs) {  // one workgroup per superblock pair
-        const size_t ns = nbk::fast_pairs_rows(n, pl.pairs);
+        const size_t ns = nbk::fast_pairs_rows(n, pl.pairs, pl.pairs_np);
         groups = std::max<size_t>(1, ns * (ns - 1) / 2);
     }
     unsigned long long *stamps = nullptr;
@@ -1761,7 +1772,7 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
                 a.stamps = stamps;
                 e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, c->scratch, c->stream)
                                                       : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, c->stream))
-                                             : pl.pairs ? nbk::launch_fast_pairs(a, pl.pairs, pl.pairs_chunk, c->scratch, c->stream)
+                                             : pl.pairs ? nbk::launch_fast_pairs(a, pl.pairs, pl.pairs_np, pl.pairs_chunk, c->scratch, c->stream)
                                              : pl.fsl ? nbk::launch_fast_sl(a, pl.ib, pl.slices, c->scratch, c->stream)
                                                       : nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, c->stream);
             }

@@ -81,15 +81,15 @@ hipError_t launch_fast_sl_phase(const StepArgs &a, uint32_t ib, uint32_t slices,
                                 hipStream_t s);  // one phase of a step in two phases (nb_launch_step_phase); rows behind the planes area
 hipError_t launch_fast_sl_kernel(const StepArgs &a, uint32_t ib, uint32_t slices, const uint32_t *flags, uint32_t generation,
                                  const float *px, const float *py, const float *pz, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
-// FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets, n_total a multiple of 256; w = waves per workgroup
-// (8, 4, 2 or 1: superblocks of 256 w bodies); chunk = bodies per chunk of the two-level walk (0 = the default: one tile up to
-// 262 144 bodies, chunks of 131 072 beyond; a multiple of 256 w); scratch = planes area (strict_bc_scratch_bytes) followed by
-// fast_pairs_scratch_floats() floats
-hipError_t launch_fast_pairs(const StepArgs &a, uint32_t w, uint32_t chunk, void *scratch, hipStream_t s);
-hipError_t launch_fast_pairs_kernels(const StepArgs &a, uint32_t w, uint32_t chunk, const uint32_t *flags, uint32_t generation, const float *px,
-                                     const float *py, const float *pz, float *scratch, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
-uint32_t fast_pairs_rows(uint32_t n_total, uint32_t w);
-size_t fast_pairs_scratch_floats(uint32_t n_total, uint32_t w, uint32_t chunk);
+// FAST pairs form (nb_nbody_sym.inc): every unordered pair once; whole sets; np = packed pairs of bodies per lane (2 or 4: blocks
+// of 128 np bodies; n_total a multiple of that), w = waves per workgroup (8, 4, 2 or 1; np = 4: up to 4): superblocks of 128 np w
+// bodies; chunk = bodies per chunk of the two-level walk (0 = the default: one tile up to 262 144 bodies, chunks of 131 072
+// beyond; a multiple of the superblock); scratch = planes area (strict_bc_scratch_bytes) followed by fast_pairs_scratch_floats() floats
+hipError_t launch_fast_pairs(const StepArgs &a, uint32_t w, uint32_t np, uint32_t chunk, void *scratch, hipStream_t s);
+hipError_t launch_fast_pairs_kernels(const StepArgs &a, uint32_t w, uint32_t np, uint32_t chunk, const uint32_t *flags, uint32_t generation,
+                                     const float *px, const float *py, const float *pz, float *scratch, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
+uint32_t fast_pairs_rows(uint32_t n_total, uint32_t w, uint32_t np);
+size_t fast_pairs_scratch_floats(uint32_t n_total, uint32_t w, uint32_t np, uint32_t chunk);
 uint32_t fast_pairs_chunk(uint32_t n_total, uint32_t chunk);  // the chunk a launch will use (>= n_total: one tile)
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);

@@ -766,18 +766,22 @@ def test_fast_scalar_load_form_every_launch_shape(nb, oracle, monkeypatch, ib, s
 
 @pytest.mark.parametrize("n,w,chunk", [(256, 8, 0), (512, 1, 0), (512, 8, 0), (2048, 2, 0), (2304, 8, 0), (2304, 4, 0), (4096, 1, 0), (4096, 8, 0),
                                        (6400, 8, 0), (6400, 2, 0), (8192, 4, 0), (32768, 0, 0),
-                                       (4096, 1, 1024), (6400, 2, 2048), (6400, 1, 256), (8192, 4, 2048), (7168, 8, 4096), (32768, 4, 8192)])
+                                       (4096, 1, 1024), (6400, 2, 2048), (6400, 1, 256), (8192, 4, 2048), (7168, 8, 4096), (32768, 4, 8192),
+                                       # eight bodies per lane (blocks of 512): -w
+                                       (512, -1, 0), (1024, -4, 0), (4096, -2, 0), (6656, -4, 0), (8192, -4, 4096), (7168, -2, 2048), (7168, -1, 512)])
 def test_fast_pairs_form(nb, oracle, monkeypatch, n, w, chunk):
     """the FAST pairs form (step_fast_pairs_kernel, nb_nbody_sym.inc; what whole sets of 32 768 to 262 144 bodies run): every
     unordered pair evaluated once and credited to both bodies -- the a-side in registers, the b-side in sums that rotate through
     the wave (DPP) and meet in LDS in a fixed order; superblocks against themselves folded the ordered way
     (pairs_diag_kernel); rows added in order (pairs_integrate_kernel).  Every workgroup width w (superblocks of 256 w bodies;
-    0 = the plan's own choice); sizes with one superblock (no pairs kernel at all), whole superblocks, and a last superblock of
+    0 = the plan's own choice; negative: eight bodies per lane instead of four, superblocks of 512 |w|); sizes with one superblock (no pairs kernel at all), whole superblocks, and a last superblock of
     one block (2 304 = 9 blocks, 6 400 = 25); sets walked in chunks (what sets above 262 144 bodies do, at test sizes); planar, 3-D and mixed data, coordinates too large for the shared reciprocal.
     Within FAST's tolerance of the oracle, deterministic from run to run, and within that tolerance of the ordered fold."""
     from nenbody_amd import _lib
 
     monkeypatch.setenv("NB_FAST_PAIRS", "1")
+    monkeypatch.setenv("NB_FAST_PAIRS_NP", "4" if w < 0 else "2")   # bodies per lane: eight (blocks of 512) or four (256)
+    w = abs(w)
     if w:
         monkeypatch.setenv("NB_FAST_PAIRS_W", str(w))
     if chunk:   # the two-level walk of sets above 262 144 bodies, at test sizes: tiles of one or two chunks, a ragged last chunk

@@ -129,12 +129,14 @@ def test_fast_pairs_form_random_problems(nb, oracle, monkeypatch, case):
     """the FAST pairs form over random block counts, workgroup widths and chunkings (one tile, several, a ragged last chunk),
     planar and 3-D: within FAST's tolerance of the oracle and bit-identical from run to run"""
     rng = np.random.default_rng(7000 + case)
-    w = int(rng.choice([1, 2, 4, 8]))
-    n = 256 * int(rng.integers(1, 28))
+    np_ = int(rng.choice([2, 4]))                                   # packed pairs of bodies per lane: blocks of 256 or 512
+    w = int(rng.choice([1, 2, 4, 8] if np_ == 2 else [1, 2, 4]))
+    n = 128 * np_ * int(rng.integers(1, 56 // np_))
     monkeypatch.setenv("NB_FAST_PAIRS", "1")
+    monkeypatch.setenv("NB_FAST_PAIRS_NP", str(np_))
     monkeypatch.setenv("NB_FAST_PAIRS_W", str(w))
     if case % 3:
-        monkeypatch.setenv("NB_FAST_PAIRS_CHUNK", str(256 * w * int(rng.integers(1, 5))))
+        monkeypatch.setenv("NB_FAST_PAIRS_CHUNK", str(128 * np_ * w * int(rng.integers(1, 5))))
     pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
     vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
     if case % 2 == 0:
@@ -149,5 +151,5 @@ def test_fast_pairs_form_random_problems(nb, oracle, monkeypatch, case):
     got_p, got_v = outs[0]
     ref_p, ref_v = oracle.run(pos, vel, 1)
     acc = np.abs(ref_v - vel).max()
-    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n} w={w}"
+    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n} w={w} np={np_}"
     assert np.abs(got_p - ref_p).max() <= 1e-5, f"case {case}"
