@@ -279,6 +279,27 @@ def test_plan_arithmetic_over_many_shapes(nb):
         assert lib.nb_scratch_bytes(ctypes.byref(odd), 131072, 16384) == 256 + 3 * 4 * 131072 + 64
 
 
+def test_phased_scratch_host_arithmetic(nb):
+    """nb_scratch_bytes_phased: a FAST step in two phases through the scalar-load kernel keeps the planes area in front of its
+    partial rows (round 3); naming a tile asks for the LDS forms, which need the rows only; STRICT has no phases."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    n, count, j_lo, j_hi = 131072, 16384, 16384, 32768
+    planes = 256 + 3 * 4 * n + 64
+    b = lib.nb_scratch_bytes_phased(ctypes.byref(fast), n, count, j_lo, j_hi)
+    assert b > planes and (b - planes) % (count * 16) == 0 and 2 <= (b - planes) // (count * 16) <= 64
+    tiled = nb.default_params(mode=nb.NB_MODE_FAST, tile=256)
+    bt = lib.nb_scratch_bytes_phased(ctypes.byref(tiled), n, count, j_lo, j_hi)
+    assert 0 < bt and bt % (count * 16) == 0
+    assert lib.nb_scratch_bytes_phased(ctypes.byref(nb.default_params()), n, count, j_lo, j_hi) == 0          # STRICT: refused
+    assert lib.nb_scratch_bytes_phased(ctypes.byref(fast), n, count, 5, 3) == 0                                # j_lo > j_hi: refused
+    # the whole set as one rank: the one-call step takes the pairs form, its phases the scalar-load fold
+    bw = lib.nb_scratch_bytes_phased(ctypes.byref(fast), n, n, 0, n)
+    assert bw > planes and (bw - planes) % (n * 16) == 0
+
+
 def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
     from nenbody_amd import _lib
 
