@@ -435,3 +435,17 @@ def test_update_instance_random_validates_without_a_device():
         if lib.nb_device_count() == 0:
             assert fn(inst.ctypes.data, 4, p.ctypes.data, 4, p.ctypes.data, 4, *tail) == _lib.NB_ERR_NO_DEVICE
     lib.nb_update_random_seed(5)   # host-side state only
+
+
+def test_graft_entry_build_agrees_with_the_binding():
+    """__graft_entry__.build() is what the driver runs every round: its closing check must follow the ABI version of the header
+    and the binding (it said `== 1` for a while after the version had moved to 2).  Not a rebuild: the check on the built library."""
+    import re
+
+    import __graft_entry__ as g
+    from nenbody_amd import _lib
+
+    src = open(g.__file__).read()
+    assert "nb_abi_version() == _lib.NB_ABI_VERSION" in src and not re.search(r"nb_abi_version\(\) == \d", src)
+    header = open(os.path.join(ROOT, "include", "nenbody.h")).read()
+    assert int(re.search(r"#define\s+NB_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.NB_ABI_VERSION == _lib.load().nb_abi_version()
