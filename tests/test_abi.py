@@ -449,3 +449,11 @@ def test_graft_entry_build_agrees_with_the_binding():
     assert "nb_abi_version() == _lib.NB_ABI_VERSION" in src and not re.search(r"nb_abi_version\(\) == \d", src)
     header = open(os.path.join(ROOT, "include", "nenbody.h")).read()
     assert int(re.search(r"#define\s+NB_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.NB_ABI_VERSION == _lib.load().nb_abi_version()
+
+
+def test_graft_entry_build_runs_to_its_end():
+    """the driver's build check, run for real (incremental: the library is up to date, the five small diagnostic tools are
+    recompiled): it must come back without raising"""
+    import __graft_entry__ as g
+
+    g.build()
