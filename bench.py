@@ -466,6 +466,17 @@ def main():
         oracle.run(pos, vel, 1, threads=threads)
         dt = time.perf_counter() - t0
         throttled = oracle.throttled_usec() - thr0
+        batched = None
+        try:  # the same arithmetic, eight bodies per AVX2 vector (bit-identical; not how the reference's loop is written)
+            if oracle.load().nbo_batched_available():
+                t0 = time.perf_counter()
+                oracle.run(pos, vel, 1, threads=threads, batched=True)
+                tb = time.perf_counter() - t0
+                batched = {"value": n / tb, "seconds": tb,
+                           "what": "the same step with eight bodies per AVX2 vector (bit-identical sums); informational: the reference's "
+                                   "loop is one body per thread at a time, which is what `value` times"}
+        except Exception as e:  # pragma: no cover
+            batched = {"error": repr(e)}
         line["cpu_baseline"] = {"value": n / dt, "unit": "body-updates/s", "cores": threads, "kind": "port",
                                 "sample": f"1 full step of the same N={n} workload ({n * n:.3e} interactions) on {threads} threads, "
                                           "C restatement of src/main.rs:404-441 (-O2 -ffp-contract=off)",
@@ -475,7 +486,8 @@ def main():
                                 "one_core_interactions_per_s": 32768.0 * 32768.0 / t_one,
                                 "interactions_per_s_per_thread": float(n) * n / dt / threads,
                                 "throttled_usec_during_run": throttled,
-                                "calibration": f"N=32768, one step: 1 thread {t_one:.3f} s, {threads} threads {t_all:.3f} s"}
+                                "calibration": f"N=32768, one step: 1 thread {t_one:.3f} s, {threads} threads {t_all:.3f} s",
+                                "avx2_batched": batched}
     watchdog.cancel()
     if rank == 0:
         print(json.dumps(line), flush=True)
