@@ -223,6 +223,28 @@ size_t nb_scratch_bytes_phased(const nb_params *params, uint32_t n_total, uint32
 int nb_launch_step_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, uint32_t j_lo, uint32_t j_hi,
                          int phase, const void *pos_in, void *pos_out, void *vel, void *scratch, size_t scratch_bytes, void *stream);
 
+/* FAST on shards with every UNORDERED pair evaluated once ("half shell").  The term of the pair (a, b) in a's sum is the negative
+ * of its term in b's (src/main.rs:428-430), so one evaluation serves both bodies even when they live on different GPUs, provided
+ * the other body's half is sent to its owner: a step then has TWO exchanges instead of one, and half the arithmetic.
+ * Rank r of P = n_total / count equal ranks (first = r * count) evaluates the pairs of its bodies with the N/2 bodies that follow
+ * them on the ring of indices; with D = nb_ring_partners() the ranks r+1 .. r+D (mod P) own those bodies.
+ *   nb_launch_ring_fold    pos_in: n_total records (the snapshot, as for nb_launch_step).  sums: (D + 1) * count records
+ *                          (x, y, z, 0), written: [0, count) = this rank's own bodies, [d * count, (d + 1) * count) = the
+ *                          sums this rank evaluated for the bodies of rank (r + d) mod P.
+ *   -- the host's second exchange: chunk d of `sums` goes to rank (r + d) mod P, which stores it as chunk d - 1 of its `recv`
+ *      (D * count records; chunk d - 1 comes from rank (r - d) mod P), d = 1..D --
+ *   nb_launch_ring_finish  adds sums[0, count) and the D received chunks in ascending distance, then src/main.rs:434-436:
+ *                          pos_out[first, first + count) and vel (count records) as nb_launch_step writes them.
+ * Every order of addition is fixed (run-to-run identical); FAST only (reassociated sums; STRICT shards keep nb_launch_step).
+ * nb_ring_partners: D >= 1; 0 when this shape does not take the form (STRICT, unequal or partial ranks, count not a multiple of
+ * 256, a set below 32 768 bodies: use nb_launch_step); or a negative nb_status.  Every rank of a job gets the same answer. */
+int nb_ring_partners(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
+size_t nb_ring_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
+int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *sums,
+                        void *scratch, size_t scratch_bytes, void *stream);
+int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *pos_out,
+                          void *vel, const void *sums, const void *recv, void *stream);
+
 /* One boids step (main.rs:443-526) for bodies [first, first+count) of a set of n_total:
  *   pos_in, vel_in    n_total records each: the snapshots old_positions / old_velocities (main.rs:459-460), read only
  *   pos_out, vel_out  n_total records each; only [first, first+count) is written (a multi-GPU caller all-gathers BOTH)

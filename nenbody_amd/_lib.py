@@ -108,6 +108,11 @@ PROTOTYPES = {
         [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
          c_void_p],
     ),
+    "nb_ring_partners": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32]),
+    "nb_ring_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32, c_uint32]),
+    "nb_launch_ring_fold": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nb_launch_ring_finish": (
+        c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_status": (c_int, [c_void_p]),
     "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),
@@ -196,7 +201,7 @@ def load() -> ctypes.CDLL:
 # the sources that define the kernels bench.py times and profiles/hbm_traffic.json meters (the two whole-set folds, the block
 # chain the shards of a multi-GPU run take, their launchers): NOT the boids controller, the aux kernels, the producer/consumer
 # form, the host-side ABI or anything outside csrc/ -- edits there leave the PMC evidence valid
-BENCHED_KERNEL_SOURCES = ("nb_kernels.hip", "nb_kernels.h", "nb_launch.inc", "nb_nbody_strict.inc", "nb_nbody_sl.inc", "nb_nbody_sym.inc", "nb_nbody_fast.inc",
+BENCHED_KERNEL_SOURCES = ("nb_kernels.hip", "nb_kernels.h", "nb_launch.inc", "nb_nbody_strict.inc", "nb_nbody_sl.inc", "nb_nbody_sym.inc", "nb_nbody_ring.inc", "nb_nbody_fast.inc",
                           "nb_nbody_bc.inc")
 
 

@@ -44,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -87,6 +87,10 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_pairs_w = read_knob("NB_FAST_PAIRS_W");
     d->fast_pairs_chunk = read_knob("NB_FAST_PAIRS_CHUNK");
     d->fast_pairs_np = read_knob("NB_FAST_PAIRS_NP");
+    d->ring = read_knob("NB_RING");
+    d->ring_np = read_knob("NB_RING_NP");
+    d->ring_ga = read_knob("NB_RING_GA");
+    d->ring_wpb = read_knob("NB_RING_WPB");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
     d->bc_prio = read_knob("NB_BC_PRIO");
     d->boids_pc = read_knob("NB_BOIDS_PC");
@@ -2057,6 +2061,197 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
         if (rc != NB_OK) return rc;
     }
     return launch_phase_planned(p, pp, n_total, first, count, j_lo, phase, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+// ---- FAST on shards, every unordered pair once ("half shell", nb_nbody_ring.inc) ------------------------------------------
+namespace {
+struct RingPlan {
+    Plan base;      // the sharing verdict (force_ieee), force_3d
+    uint32_t np;    // packed pairs of bodies per lane: 4 (blocks of 512) where the shard is whole blocks of 512, else 2 (256)
+    uint32_t ga, wpb;
+    uint32_t partners;  // 0: this shape does not take the form
+};
+// Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and a set large enough that the
+// rows and the second exchange pay (the same line as the one-GPU pairs form: 32 768 bodies).  NB_RING=0/1 decides outright
+// where the shape allows it; NB_RING_NP / NB_RING_GA / NB_RING_WPB name the kernel's shape (tests, tools/).
+int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, RingPlan *out, std::string *err)
+{
+    int rc = make_plan(p, n_total, count, &out->base, err);
+    if (rc != NB_OK) return rc;
+    const DebugOverrides &dbg = overrides();
+    out->partners = 0;
+    out->np = (count % 512u == 0u) ? 4u : 2u;
+    if (dbg.ring_np.set && (dbg.ring_np.v == 2u || dbg.ring_np.v == 4u)) out->np = dbg.ring_np.v;
+    out->ga = dbg.ring_ga.or_else(0u);
+    out->wpb = dbg.ring_wpb.or_else(0u) & ~3u;
+    if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
+    if (!dbg.ring.or_else(n_total >= 32768u ? 1u : 0u)) return NB_OK;
+    out->partners = nbk::ring_partners(n_total, first, count, out->np);
+    return NB_OK;
+}
+size_t ring_scratch_bytes(const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count)
+{
+    return nbk::strict_bc_scratch_bytes(n_total) + nbk::ring_scratch_floats(n_total, first, count, rp.np, rp.ga, rp.wpb) * sizeof(float);
+}
+int cached_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, const RingPlan **out, std::string *err)
+{
+    struct Entry {
+        bool valid = false;
+        nb_params p{};
+        uint32_t n_total = 0, first = 0, count = 0, generation = 0;
+        RingPlan rp{};
+    };
+    constexpr int kEntries = 2;
+    thread_local Entry cache[kEntries];
+    thread_local int next = 0;
+    const uint32_t gen = overrides().generation;
+    for (int i = 0; i < kEntries; ++i) {
+        const Entry &e = cache[i];
+        if (e.valid && e.n_total == n_total && e.first == first && e.count == count && e.generation == gen && std::memcmp(&e.p, &p, sizeof(p)) == 0) {
+            *out = &e.rp;
+            return NB_OK;
+        }
+    }
+    RingPlan rp;
+    int rc = make_ring_plan(p, n_total, first, count, &rp, err);
+    if (rc != NB_OK) return rc;
+    Entry &e = cache[next];
+    next = (next + 1) % kEntries;
+    e.valid = true;
+    e.p = p;
+    e.n_total = n_total;
+    e.first = first;
+    e.count = count;
+    e.generation = gen;
+    e.rp = rp;
+    *out = &e.rp;
+    return NB_OK;
+}
+nbk::StepArgs ring_step_args(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                             void *pos_out, void *vel)
+{
+    nbk::StepArgs a{};
+    a.pos_in = (const float4 *)pos_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel = (float4 *)vel;
+    a.n_total = n_total;
+    a.first = first;
+    a.count = count;
+    a.dt = p.dt;
+    a.G = p.G;
+    a.bias = p.bias;
+    a.force_ieee = rp.base.force_ieee;
+    a.force_3d = rp.base.force_3d;
+    return a;
+}
+int launch_ring_fold_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                             void *sums, void *scratch, hipStream_t stream, std::string *err)
+{
+    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, nullptr, nullptr);
+    hipError_t e = nbk::launch_fast_ring(a, rp.np, rp.ga, rp.wpb, scratch, (float4 *)sums, stream);
+    if (e != hipSuccess) {
+        *err = std::string("nb: kernel launch failed (ring fold): ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+int launch_ring_finish_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                               void *pos_out, void *vel, const void *sums, const void *recv, hipStream_t stream, std::string *err)
+{
+    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, pos_out, vel);
+    hipError_t e = nbk::launch_ring_finish(a, (const float4 *)sums, (const float4 *)recv, rp.partners, stream);
+    if (e != hipSuccess) {
+        *err = std::string("nb: kernel launch failed (ring finish): ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+}  // namespace
+
+NB_EXPORT int nb_ring_partners(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    const RingPlan *rp = nullptr;
+    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    return (int)rp->partners;
+}
+
+NB_EXPORT size_t nb_ring_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    RingPlan rp;
+    std::string err;
+    if (make_ring_plan(p, n_total, first, count, &rp, &err) != NB_OK || rp.partners == 0u) return 0;
+    return ring_scratch_bytes(rp, n_total, first, count);
+}
+
+NB_EXPORT int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *sums,
+                                  void *scratch, size_t scratch_bytes, void *stream)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    if (!pos_in || !sums || !scratch) {
+        g_tls_error = "nb_launch_ring_fold: pos_in, sums and scratch must be non-null";
+        return NB_ERR_INVALID;
+    }
+    const RingPlan *rp = nullptr;
+    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (rp->partners == 0u) {
+        g_tls_error = "nb_launch_ring_fold: this shape does not take the pairs form on shards (nb_ring_partners() == 0): use nb_launch_step";
+        return NB_ERR_UNSUPPORTED;
+    }
+    if (scratch_bytes < ring_scratch_bytes(*rp, n_total, first, count)) {
+        g_tls_error = "nb_launch_ring_fold: scratch smaller than nb_ring_scratch_bytes()";
+        return NB_ERR_INVALID;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (!stream) {
+        rc = select_device_of(pos_in, &g_tls_error);
+        if (rc != NB_OK) return rc;
+    }
+    return launch_ring_fold_planned(p, *rp, n_total, first, count, pos_in, sums, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+NB_EXPORT int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                                    void *pos_out, void *vel, const void *sums, const void *recv, void *stream)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    if (!pos_in || !pos_out || !vel || !sums || !recv || pos_in == pos_out) {
+        g_tls_error = "nb_launch_ring_finish: pos_in, pos_out, vel, sums, recv must be non-null and pos_out must not alias pos_in";
+        return NB_ERR_INVALID;
+    }
+    const RingPlan *rp = nullptr;
+    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (rp->partners == 0u) {
+        g_tls_error = "nb_launch_ring_finish: this shape does not take the pairs form on shards (nb_ring_partners() == 0)";
+        return NB_ERR_UNSUPPORTED;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (!stream) {
+        rc = select_device_of(pos_in, &g_tls_error);
+        if (rc != NB_OK) return rc;
+    }
+    return launch_ring_finish_planned(p, *rp, n_total, first, count, pos_in, pos_out, vel, sums, recv, (hipStream_t)stream, &g_tls_error);
 }
 
 NB_EXPORT int nb_diag_rccl_solo(int on)

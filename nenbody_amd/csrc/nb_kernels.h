@@ -91,6 +91,18 @@ hipError_t launch_fast_pairs_kernels(const StepArgs &a, uint32_t w, uint32_t np,
 uint32_t fast_pairs_rows(uint32_t n_total, uint32_t w, uint32_t np);
 size_t fast_pairs_scratch_floats(uint32_t n_total, uint32_t w, uint32_t np, uint32_t chunk);
 uint32_t fast_pairs_chunk(uint32_t n_total, uint32_t chunk);  // the chunk a launch will use (>= n_total: one tile)
+// FAST pairs form on a SHARD (nb_nbody_ring.inc, "half shell"): the rank's blocks evaluate the pairs with the blocks that follow them
+// on the ring, their own sums stay, the other bodies' sums go into `sums` (rank-relative records: [0, count) own, [d count,
+// (d + 1) count) for rank + d, d = 1..partners) for the step's second exchange; launch_ring_finish adds what the `partners` ranks
+// behind sent (recv: partners * count records, ascending distance) and integrates.  np: packed pairs of bodies per lane (2 or 4);
+// ga: a-blocks per launch (0: default), wpb: waves per a-block (0: default).  scratch = planes area + ring_scratch_floats() floats.
+// Shapes: count divides n_total (>= 2 ranks), first a multiple of count, count a multiple of 128 np.
+uint32_t ring_partners(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np);  // 0: the shape cannot take the form
+size_t ring_scratch_floats(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb);
+hipError_t launch_fast_ring(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, void *scratch, float4 *sums, hipStream_t s);
+hipError_t launch_fast_ring_kernels(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, const uint32_t *flags, uint32_t generation,
+                                    const float *px, const float *py, const float *pz, float *scratch, float4 *sums, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
+hipError_t launch_ring_finish(const StepArgs &a, const float4 *sums, const float4 *recv, uint32_t partners, hipStream_t s);
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
 hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);

@@ -34,6 +34,7 @@
 //   nb_nbody_bc.inc      STRICT block-chain kernel for small shards        (this unit)
 //   nb_nbody_sl.inc      STRICT scalar-load kernel: whole sets and large shards, no LDS, no barrier  (its own unit)
 //   nb_nbody_sym.inc     FAST pairs form: every unordered pair evaluated once, whole sets       (the scalar-load unit)
+//   nb_nbody_ring.inc    FAST pairs form on a shard ("half shell"): a second exchange carries the other GPUs' halves  (the scalar-load unit)
 //   nb_nbody_fast.inc    FAST kernels + fixed-order combine               (this unit)
 //   nb_aux.inc           model matrices, cameras, random walk, self-test  (this unit)
 //   nb_boids.inc         boids controller, one-lane and producer/consumer (SLP-off unit)
@@ -57,6 +58,7 @@ static constexpr int kWaves = kBlock / 64;
 #if defined(NBK_SL_TU)
 #include "nb_nbody_sl.inc"    // alone in its unit: compiled without the machine scheduler (its source order is its issue order)
 #include "nb_nbody_sym.inc"   // FAST, every unordered pair once: hand-ordered like the scalar-load folds
+#include "nb_nbody_ring.inc"  // the same on a shard of a multi-GPU job: the blocks on a ring, each against the half that follows it
 #elif defined(NBK_NOSLP_TU)
 #include "nb_boids.inc"
 #else

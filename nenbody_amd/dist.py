@@ -71,6 +71,33 @@ class HipBackend:
             check(self.lib.nb_launch_step_phase(ctypes.byref(params), n_total, first, count, j_lo, j_hi, phase, pos_in.data_ptr(),
                                                 pos_out.data_ptr(), vel.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
 
+    # -- FAST on shards, every unordered pair once ("half shell": nb_launch_ring_fold / _finish, include/nenbody.h) ----------
+    def ring_partners(self, params: NbParams, n_total: int, first: int, count: int) -> int:
+        """D >= 1: the ranks in front of this one that own bodies of its pair lists; 0: this shape keeps ``step``."""
+        d = int(self.lib.nb_ring_partners(ctypes.byref(params), n_total, first, count))
+        if d < 0:
+            check(d)
+        return d
+
+    def ring_scratch_bytes(self, params: NbParams, n_total: int, first: int, count: int) -> int:
+        return int(self.lib.nb_ring_scratch_bytes(ctypes.byref(params), n_total, first, count))
+
+    def ring_fold(self, params, n_total, first, count, pos_in, sums, scratch) -> None:
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        with torch.cuda.device(pos_in.device):
+            check(self.lib.nb_launch_ring_fold(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), sums.data_ptr(),
+                                               scratch.data_ptr(), scratch.numel(), stream))
+
+    def ring_finish(self, params, n_total, first, count, pos_in, pos_out, vel, sums, recv) -> None:
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        with torch.cuda.device(pos_in.device):
+            check(self.lib.nb_launch_ring_finish(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
+                                                 vel.data_ptr(), sums.data_ptr(), recv.data_ptr(), stream))
+
     def instances(self, count, pos, vel, inst) -> None:
         import torch
 
@@ -94,7 +121,8 @@ class ShardedScene:
     """
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, device=None, group=None,
-                 backend=None, rank: Optional[int] = None, world: Optional[int] = None, overlap: bool = False):
+                 backend=None, rank: Optional[int] = None, world: Optional[int] = None, overlap: bool = False,
+                 ring: Optional[bool] = None):
         import torch
         import torch.distributed as dist
 
@@ -132,9 +160,23 @@ class ShardedScene:
         if self.count:
             vrec[: self.count, :3] = torch.from_numpy(vel[self.first:self.first + self.count])
         self.vel = vrec.to(self.device)
-        self.overlap = bool(overlap) and self.params.mode == _lib.NB_MODE_FAST and world > 1
+        # FAST, equal ranks: every unordered pair once, the other ranks' halves leaving in a SECOND exchange per step
+        # (ring=None: where the library plans it; True: required; False: the ordered fold with its one exchange)
+        self.partners = 0
+        if ring is not False and world > 1 and self.params.mode == _lib.NB_MODE_FAST and self.n == self.slot * world \
+                and hasattr(self.backend, "ring_partners"):
+            self.partners = self.backend.ring_partners(self.params, self.n, self.first, self.count)
+        if ring and not self.partners:
+            raise ValueError("ring=True: this shape does not take the pairs form on shards (FAST, equal ranks of whole blocks)")
+        self.sums = self.recv = None
+        if self.partners:
+            self.sums = torch.zeros(((self.partners + 1) * self.count, 4), dtype=torch.float32, device=self.device)
+            self.recv = torch.zeros((self.partners * self.count, 4), dtype=torch.float32, device=self.device)
+        self.overlap = bool(overlap) and self.params.mode == _lib.NB_MODE_FAST and world > 1 and not self.partners
         self._pending = None     # the exchange in flight (overlap): a torch.distributed work handle, or None
-        if self.overlap:
+        if self.partners:
+            sb = self.backend.ring_scratch_bytes(self.params, self.n, self.first, self.count)
+        elif self.overlap:
             sb = self.backend.scratch_bytes_phased(self.params, self.n, self.count, self.first, self.first + self.count) if self.count else 0
         else:
             sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
@@ -161,6 +203,24 @@ class ShardedScene:
             self.dist.all_gather_into_tensor(full, mine.cpu(), group=self.group)
             buf.copy_(full)
         return None  # these paths complete before returning
+
+    # -- the pairs form's second exchange: chunk d of `sums` goes to rank + d, chunk d - 1 of `recv` comes from rank - d --------
+    def _ring_exchange(self) -> None:
+        dist, S = self.dist, self.count
+        on_host = dist.get_backend(self.group) != "nccl" and self.sums.device.type != "cpu"
+        sums = self.sums.cpu() if on_host else self.sums   # rehearsal path (gloo with device buffers): stage through the host
+        recv = self.torch.empty(self.recv.shape, dtype=self.recv.dtype) if on_host else self.recv
+        ops = []
+        for d in range(1, self.partners + 1):
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            if self.group is not None:
+                to, frm = dist.get_global_rank(self.group, to), dist.get_global_rank(self.group, frm)
+            ops.append(dist.P2POp(dist.isend, sums[d * S:(d + 1) * S], to, self.group, tag=d))
+            ops.append(dist.P2POp(dist.irecv, recv[(d - 1) * S:d * S], frm, self.group, tag=d))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()   # RCCL: the current stream waits, not the host
+        if on_host:
+            self.recv.copy_(recv)
 
     def _wait_pending(self) -> None:
         """overlap: make the current stream wait for the exchange in flight (no host wait with RCCL)"""
@@ -211,7 +271,12 @@ class ShardedScene:
     # -- one step: local update, then the exchange ------------------------------------------------------
     def step(self) -> None:
         src, dst = self.pos[self.cur], self.pos[self.cur ^ 1]
-        if self.overlap:
+        if self.partners:
+            self.backend.ring_fold(self.params, self.n, self.first, self.count, src, self.sums, self.scratch)
+            self._ring_exchange()
+            self.backend.ring_finish(self.params, self.n, self.first, self.count, src, dst, self.vel, self.sums, self.recv)
+            self._all_gather_slots(dst)
+        elif self.overlap:
             # src's other slots may still be landing; this rank's own slot of src was written by its own last step
             lo, hi = self.first, self.first + self.count
             if self.count:

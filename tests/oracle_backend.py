@@ -49,6 +49,47 @@ class OracleBackend:
         pos_out[first:first + count, 3] = 0
         vel[:count, :3] = torch.from_numpy(v)
 
+    # -- FAST on shards, every unordered pair once (nb_launch_ring_fold / nb_launch_ring_finish): the same decomposition at a block
+    #    size of ONE body -- body I evaluates its pairs with the h(I) bodies that follow it on the ring, keeps its own halves and
+    #    files the others under the offset of the body they belong to; numpy binary32, FAST tolerances apply -----------------------
+    @staticmethod
+    def _fwd(i, n):
+        return (n - 1) // 2 if n % 2 else n // 2 - 1 + (1 if i < n // 2 else 0)
+
+    def ring_partners(self, params, n_total, first, count):
+        if params.mode != 1 or count == 0 or count >= n_total or n_total % count or first % count:
+            return 0
+        hmax = (n_total - 1) // 2 if n_total % 2 else n_total // 2
+        return -(-(count + hmax) // count) - 1
+
+    def ring_scratch_bytes(self, params, n_total, first, count):
+        return 16
+
+    def ring_fold(self, params, n_total, first, count, pos_in, sums, scratch):
+        old = pos_in[:n_total, :3].contiguous().numpy()
+        out = np.zeros((sums.shape[0], 3), np.float32)
+        for l in range(count):
+            i = first + l
+            js = (i + 1 + np.arange(self._fwd(i, n_total))) % n_total
+            if not len(js):
+                continue
+            d = old[js] - old[i]
+            t = d / ((d * d).sum(axis=1, dtype=np.float32) + np.float32(params.bias))[:, None]
+            out[l] += t.sum(axis=0, dtype=np.float32)
+            np.subtract.at(out, l + 1 + np.arange(len(js)), t)   # offsets behind this rank's first body: the ring, unrolled
+        sums[:, :3] = torch.from_numpy(out)
+        sums[:, 3] = 0
+
+    def ring_finish(self, params, n_total, first, count, pos_in, pos_out, vel, sums, recv):
+        old = pos_in[:n_total, :3].contiguous().numpy()
+        a = sums[:count, :3].numpy().copy()
+        for d in range(recv.shape[0] // count):
+            a = a + recv[d * count:(d + 1) * count, :3].numpy()
+        v = vel[:count, :3].numpy() + (a * np.float32(params.G)) * np.float32(params.dt)
+        pos_out[first:first + count, :3] = torch.from_numpy(v + old[first:first + count])
+        pos_out[first:first + count, 3] = 0
+        vel[:count, :3] = torch.from_numpy(v)
+
     def instances(self, count, pos, vel, inst):
         m = oracle.instances(pos[:count, :3].contiguous().numpy(), vel[:count, :3].contiguous().numpy())
         inst[:count] = torch.from_numpy(m.reshape(count, 16))

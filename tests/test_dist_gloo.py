@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False):
+def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,10 +33,29 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False):
 
         pos, vel = oracle.init_state(n, seed=4321)
         pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
-        params = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST) if overlap else None
-        sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap)
+        params = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST) if (overlap or ring) else None
+        sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap, ring=True if ring else False)
         assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap
-        if boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
+        if ring:   # two exchanges per step: the halves that belong to the ranks in front (point to point), then the positions
+            assert sc.partners == ring and not sc.overlap
+            sent, gathers = [], []
+            real_batch, real_gather = dist.batch_isend_irecv, dist.all_gather_into_tensor
+
+            def counting_batch(ops):
+                sent.append(sorted((op.op.__name__, op.peer, op.tensor.numel()) for op in ops))
+                return real_batch(ops)
+
+            def counting_gather(out, inp, *a, **kw):
+                gathers.append(out.numel())
+                return real_gather(out, inp, *a, **kw)
+
+            dist.batch_isend_irecv, dist.all_gather_into_tensor = counting_batch, counting_gather
+            sc.step_n(k)
+            dist.batch_isend_irecv, dist.all_gather_into_tensor = real_batch, real_gather
+            want = sorted([("isend", (rank + d) % world, sc.count * 4) for d in range(1, ring + 1)] +
+                          [("irecv", (rank - d) % world, sc.count * 4) for d in range(1, ring + 1)])
+            assert sent == [want] * k and gathers == [world * sc.slot * 4] * k, (sent, gathers)
+        elif boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
             gathers = []
             real = dist.all_gather_into_tensor
 
@@ -124,3 +143,34 @@ def test_sharded_fast_with_overlapped_exchange(tmp_path, oracle, world, n, k):
 
     sc = nenbody_amd.ShardedScene(pos, vel, backend=OracleBackend(), device="cpu", overlap=True)   # STRICT, world 1
     assert not sc.overlap
+
+
+@pytest.mark.parametrize("world,n,k,partners", [(2, 64, 4, 1), (3, 48, 3, 2), (3, 51, 3, 2), (4, 64, 3, 2)])
+def test_sharded_fast_pairs_once_with_second_exchange(tmp_path, oracle, world, n, k, partners):
+    """ring=True (FAST, equal ranks): every unordered pair is evaluated once, by the rank that owns the body further back on the
+    ring of indices; the other body's half travels to its owner in a second, point-to-point exchange (nb_launch_ring_fold /
+    nb_launch_ring_finish).  The worker checks the collectives of every step (D sends to the ranks in front, D receives from the
+    ranks behind, one all-gather); here: every rank's replica matches the unsharded run to FAST's tolerance."""
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), False, False, partners), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
+
+
+def test_ring_needs_equal_ranks(oracle):
+    """a ragged split (or STRICT) keeps the ordered fold and its one exchange; asking for the ring there is an error"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import nenbody_amd
+    from oracle_backend import OracleBackend
+
+    pos, vel = oracle.init_state(50, seed=1)
+    fast = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST)
+    sc = nenbody_amd.ShardedScene(pos, vel, fast, backend=OracleBackend(), device="cpu", rank=1, world=3)   # 17 + 17 + 16
+    assert sc.partners == 0
+    with pytest.raises(ValueError):
+        nenbody_amd.ShardedScene(pos, vel, fast, backend=OracleBackend(), device="cpu", rank=1, world=3, ring=True)
+    sc = nenbody_amd.ShardedScene(pos[:48], vel[:48], backend=OracleBackend(), device="cpu", rank=1, world=3)   # STRICT
+    assert sc.partners == 0
