@@ -8,7 +8,9 @@
 Workload (BASELINE.json): N = 131 072 bodies, reference initial distributions (src/main.rs:738-747, seeded),
 reference constants (src/main.rs:411-413); a "step" is one update_instance_nbody over the whole set.  With N
 GPUs the set is sharded by index range (strong scaling: total work fixed) and positions are all-gathered
-once per step (RCCL).  Inputs are resident in HBM before the timed region.
+once per step (RCCL); FAST on equal ranks evaluates every unordered pair once across the ranks, the other bodies' halves
+leaving in a second, point-to-point exchange per step (--no-ring: the ordered fold and its one exchange).  Inputs are
+resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0.  `value` = body-updates/s = N * steps / s of the whole job, STRICT arithmetic (the
 reference's own, bit for bit) unless --mode fast.  `roofline` prices the pair-fold kernel against the fp32 vector peak
@@ -31,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBPS = 8000.0            # same guide: HBM3E ~8 TB/s
+SPEC_LANE_OPS_PER_S = PEAK_FP32_VECTOR_TFLOPS * 1e12 / 2.0   # one vector operation per lane per cycle (the flop peak counts an FMA twice)
 BYTES_PER_BODY_STEP = 64          # algorithmic HBM bytes: 16-B position + 16-B velocity record, read and written once
 FLOP_PER_INTERACTION = 18         # src/main.rs:428-430 as written: 3 sub, 3 mul + 2 add, 1 add, 3 mul, 3 div, 3 add
 # What the kernels execute per interaction on the vector ALU, in full-rate lane-ops + quarter-rate
@@ -104,11 +107,13 @@ def preheat(step, torch, dist, world, dev, ms):
     return int(k.item()) + 2
 
 
-def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False):
+def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False, ring=None, preheat_ms=None):
+    """ring: None = the library's plan (FAST on equal ranks of a multi-GPU job: every unordered pair once, two exchanges per
+    step), False = the ordered fold with its one exchange."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     params = nb.default_params(mode=mode)
-    sc = nb.ShardedScene(pos, vel, params, overlap=overlap)
+    sc = nb.ShardedScene(pos, vel, params, overlap=overlap, ring=ring)
     dev = sc.device
 
     def fence():
@@ -120,37 +125,48 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     if world > 1:
         # untimed: bring the communicator and its channels up even when --warmup 0 (the target buffer is the scratch side)
         sc._all_gather_slots(sc.pos[sc.cur ^ 1])
-    pre = preheat(sc.step, torch, dist, world, dev, args.preheat_ms)
+        if sc.partners:
+            sc._ring_exchange()   # the point-to-point channels of the second exchange too
+    pre = preheat(sc.step, torch, dist, world, dev, args.preheat_ms if preheat_ms is None else preheat_ms)
     for _ in range(warmup):
         sc.step()
-    # kernel-only timing: events on the stream the kernel is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    real_step = sc.backend.step
+    # kernel-only timing: events on the stream the kernels are launched on (torch's current stream), around every launch call of
+    # a step (one: nb_launch_step; the pairs form on shards: nb_launch_ring_fold and nb_launch_ring_finish, the exchange between
+    # them outside the events)
+    calls = ("ring_fold", "ring_finish") if sc.partners else ("step",)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * len(calls))]
+    real = {name: getattr(sc.backend, name) for name in calls}
+    used = [0]
 
-    def timed_step(*a, **kw):
-        e0, e1 = ev[timed_step.i]
-        timed_step.i += 1
-        e0.record()
-        real_step(*a, **kw)
-        e1.record()
+    def timed(fn):
+        def call(*a, **kw):
+            e0, e1 = ev[used[0]]
+            used[0] += 1
+            e0.record()
+            fn(*a, **kw)
+            e1.record()
+        return call
 
-    timed_step.i = 0
-    sc.backend.step = timed_step
+    for name in calls:
+        setattr(sc.backend, name, timed(real[name]))
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         sc.step()
     fence()
     t1 = time.perf_counter()
-    sc.backend.step = real_step
+    for name in calls:
+        setattr(sc.backend, name, real[name])
     sc.sync()  # nb_launch_status: a kernel-reported failure fails the bench instead of timing garbage
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     # (the overlapped form launches its two phases through step_phase: no per-kernel events there, wall time only)
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if sc.count and timed_step.i == len(ev) else 0.0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps if sc.count and used[0] == len(ev) else 0.0
+    kernels = (["step_fast_ring_kernel", "planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"] if sc.partners
+               else step_kernels(nb, mode, sc.n, sc.count))
     return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
-            "kernels": step_kernels(nb, mode, sc.n, sc.count), "mode": "fast" if mode == nb.NB_MODE_FAST else "strict"}
+            "kernels": kernels, "mode": "fast" if mode == nb.NB_MODE_FAST else "strict", "partners": sc.partners, "world": world}
 
 
 def main():
@@ -165,6 +181,9 @@ def main():
                     help="untimed steps for this long in front of every leg's warm-up steps, until the clock ramp after the idle gap is over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the informational legs (other mode, 3-D data, boids)")
+    ap.add_argument("--no-ring", action="store_true",
+                    help="multi-GPU FAST: keep the ordered fold with its one exchange per step instead of the pairs form on shards "
+                         "(every unordered pair once, two exchanges per step)")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="multi-GPU only: also time FAST with the exchange overlapped (ShardedScene(overlap=True)); off by default "
                          "so that nothing untried on hardware can cost the scaling run its exit code")
@@ -214,25 +233,48 @@ def main():
     n = args.n
     pos, vel = nb.init_state(n, 1234)
     primary = nb.NB_MODE_STRICT if args.mode == "strict" else nb.NB_MODE_FAST
-    res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel)
+    res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel, ring=False if args.no_ring else None)
 
     def summarise(r, data="planar"):
         steps_per_s = r["steps"] / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
-        achieved = FLOP_PER_INTERACTION * r["count"] * r["n"] / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        nominal = FLOP_PER_INTERACTION * r["count"] * r["n"] / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        # Pair EVALUATIONS a launch executes.  The ordered folds evaluate every ordered pair the reference does (count x n, self
+        # pairs included).  The pairs forms evaluate an unordered pair ONCE for both bodies: a whole set n^2 / 2 + 1 024 n (the pairs
+        # between superblocks of 2 048 bodies once, the pairs inside them as an ordered fold); a rank of the multi-GPU form
+        # count x n / 2 + 256 count (its blocks against the half of the ring behind them + each block of 512 against itself).
+        form = r["kernels"][0]
+        ex = dict(executed_ops(r["mode"], data, "step_fast_pairs_kernel" if form == "step_fast_ring_kernel" else form))
+        if form == "step_fast_pairs_kernel":
+            superblock = 2048.0 if r["n"] >= 131072 and r["n"] % 512 == 0 else 1024.0   # (nb_api.hip:make_plan)
+            evaluations = float(r["n"]) * r["n"] / 2.0 + superblock / 2.0 * r["n"]
+        elif form == "step_fast_ring_kernel":
+            evaluations = float(r["count"]) * r["n"] / 2.0 + 256.0 * r["count"]
+        else:
+            evaluations = float(r["count"]) * r["n"]
+        achieved = FLOP_PER_INTERACTION * evaluations / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        lane_ops = (ex["full_rate_ops"] + ex["v_rcp_f32"]) * float(r["count"]) * r["n"] / kernel_s if kernel_s > 0 else 0.0
         traffic, source = committed_traffic(nb, r["kernels"], r["n"], r["count"])
         roof = {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                "frac_is": "nominal: the reference's 18 flop per ordered pair (flop_per_interaction) over the spec fp32 vector peak"
-                           + ("; the pairs form evaluates each unordered pair once for both bodies, so it executes about half of that "
-                              "nominal work and can pass 1.0" if r["kernels"][0] == "step_fast_pairs_kernel" else ""),
+                "frac_is": "18 flop (the reference's count per pair, src/main.rs:428-430) x the pair evaluations the launch EXECUTES "
+                           "(pair_evaluations_per_launch) / kernel time, over the spec fp32 vector peak"
+                           + (": this form evaluates an unordered pair once for both bodies, so it executes about half of the reference's "
+                              "ordered evaluations; frac_nominal prices the reference's n^2 ordered pairs instead and may pass 1"
+                              if evaluations != float(r["count"]) * r["n"] else ""),
+                "frac_nominal": nominal / PEAK_FP32_VECTOR_TFLOPS, "achieved_nominal": nominal,
+                "frac_executed": lane_ops / SPEC_LANE_OPS_PER_S,
+                "frac_executed_is": "vector lane operations the kernel executes per second (executed_per_interaction: full-rate ops + "
+                                    "reciprocals, per ordered pair of the reference) over the spec issue rate of one operation per lane per "
+                                    "cycle (256 CUs x 128 lanes x 2.4 GHz = 7.86e13/s; an FMA counts once here, twice in the flop peak)",
+                "pair_evaluations_per_launch": evaluations,
                 "bound_note": "fp32 vector ALU (SURVEY.md 8d): an all-pairs fp32 fold is neither HBM- nor MFMA-bound; see 'hbm'",
                 "traffic": traffic, "traffic_unit": "bytes/step (HBM, PMC)", "traffic_source": source,
                 "algorithmic_bytes_per_launch": BYTES_PER_BODY_STEP * r["count"],
                 "kernel": r["kernels"][0], "kernels_per_step": r["kernels"],
                 "kernel_ms": r["kernel_ms"],
                 "flop_per_interaction": FLOP_PER_INTERACTION, "interactions_per_launch": float(r["count"]) * r["n"],
-                "executed_per_interaction": executed_ops(r["mode"], data, r["kernels"][0])}
+                "executed_per_interaction": ex}
         if traffic is not None and kernel_s > 0:  # how far from the HBM roofline the same launch is
             gbps = traffic / kernel_s / 1e9
             roof["hbm"] = {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}
@@ -261,7 +303,10 @@ def main():
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL backend, not a measurement)",
         "config": {"workload": f"N={n} bodies, fp32, reference init distributions (seed 1234; planar: z = 0 as main.rs:740,745), "
                                "dt=0.1 G=0.001 bias=1e-7",
-                   "mode": args.mode, "sharding": f"index range x{world}, all-gather of positions per step",
+                   "mode": args.mode,
+                   "sharding": f"index range x{world}, all-gather of positions per step" +
+                               (f"; every unordered pair evaluated once, the halves of the {res['partners']} ranks in front leaving in a second, "
+                                "point-to-point exchange per step" if res["partners"] else ""),
                    "tile": "library default"},
         "interactions_per_s": s["interactions_per_s"],
         "roofline": s["roofline"],
@@ -269,8 +314,11 @@ def main():
         # steps.  The system is chaotic: only arithmetic identical to the reference's holds the second
         # line, and an exact binary32 divide costs 4 vector ops where the flop count says 1, which caps STRICT near 1/3.
         "targets": {"roofline_40pct_met_by": "fast", "parity_1000_steps_met_by": "strict", "both_met_by": None,
-                    "note": "STRICT = the reference's arithmetic bit for bit (|dr| = 0 at any horizon) at ~0.32 of the fp32 "
-                            "peak; FAST = same law reassociated, above 0.40, |dr| < 1e-4 for ~100-200 steps only"},
+                    "note": "STRICT = the reference's arithmetic bit for bit (|dr| = 0 on every body after every one of 1 000 steps at this "
+                            "size) at ~0.36 of the fp32 peak; FAST = same law reassociated, above 0.40 -- the system is chaotic, and at "
+                            "N = 131 072 FAST's WORST body leaves |dr| < 1e-4 at step 2, the 99.9 % quantile at step 8, the median body at "
+                            "about step 30 (at N = 1 024: all bodies within 1e-4 for 100-200 steps); a one-ulp change of one coordinate in "
+                            "STRICT's own input diverges as fast (tests/test_gpu_parity.py)"},
     }
 
     # Everything after this point is informational.  If it wedges (a collective that never completes, say), the
@@ -294,11 +342,40 @@ def main():
         other_mode = nb.NB_MODE_FAST if primary == nb.NB_MODE_STRICT else nb.NB_MODE_STRICT
         leg["name"] = "other_mode"
         try:
-            o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel))
+            # (multi-GPU: FAST as the ordered fold with its one exchange here; the pairs form on shards is a leg of its own below)
+            o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel, ring=False))
             line["other_mode"] = {"mode": "fast" if primary == nb.NB_MODE_STRICT else "strict",
                                   "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
         except Exception as e:  # pragma: no cover
             line["other_mode"] = {"error": repr(e)}
+
+        if world > 1 and not (primary == nb.NB_MODE_FAST and res["partners"]):
+            leg["name"] = "fast_pairs_on_shards"
+            try:
+                r2 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel)
+                if r2["partners"]:
+                    o = summarise(r2)
+                    line["fast_pairs_on_shards"] = {"what": "FAST, every unordered pair evaluated once across the ranks: a rank folds its bodies "
+                                                            "against the half of the ring behind them, the other bodies' halves leave in a second "
+                                                            "(point-to-point) exchange per step (nb_launch_ring_fold / nb_launch_ring_finish)",
+                                                    "partners": r2["partners"], "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"],
+                                                    "roofline": o["roofline"]}
+            except Exception as e:  # pragma: no cover
+                line["fast_pairs_on_shards"] = {"error": repr(e)}
+
+        # what a leg costs WITHOUT the preheat: five timed steps right behind the idle gap of a fresh scene (the clock ramp included)
+        leg["name"] = "unpreheated"
+        try:
+            cold = {}
+            for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
+                time.sleep(0.2)
+                r0 = time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=5, preheat_ms=0.0,
+                               ring=False if args.no_ring else None)
+                cold[name] = {"ms_per_step": 1e3 * r0["elapsed_s"] / r0["steps"], "kernel_ms": r0["kernel_ms"]}
+            line["unpreheated"] = {"what": f"the same legs with --preheat-ms 0: {args.warmup} warm-up + 5 timed steps behind the idle gap a fresh "
+                                           "scene leaves (the part ramps its clock for 30-40 ms after such a gap)", "steps": 5, **cold}
+        except Exception as e:  # pragma: no cover
+            line["unpreheated"] = {"error": repr(e)}
 
         if args.overlap_leg and world > 1:
             leg["name"] = "fast_overlap"
@@ -404,8 +481,11 @@ def main():
             for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
                 mhz, cyc, kms = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
                 pm = nb.default_params(mode=mode)
-                nb._lib.check(nb.load().nb_diag_step_clock(ctypes.byref(pm), n, 0.3, ctypes.byref(mhz), ctypes.byref(cyc), ctypes.byref(kms)))
-                held[name] = {"held_clock_mhz": mhz.value, "wave_cycles": cyc.value, "kernel_ms": kms.value}
+                try:   # (shapes whose kernel is not stamped -- block chain, LDS forms at small --n -- answer NB_ERR_UNSUPPORTED: keep the streams)
+                    nb._lib.check(nb.load().nb_diag_step_clock(ctypes.byref(pm), n, 0.3, ctypes.byref(mhz), ctypes.byref(cyc), ctypes.byref(kms)))
+                    held[name] = {"held_clock_mhz": mhz.value, "wave_cycles": cyc.value, "kernel_ms": kms.value}
+                except nb.NbError as e:
+                    held[name] = {"held_clock_mhz": None, "wave_cycles": None, "kernel_ms": None, "why": str(e)}
             ex = line["roofline"]["executed_per_interaction"]
             slots = ex["full_rate_ops"] + 4.0 * ex["v_rcp_f32"]   # a quarter-rate v_rcp_f32 takes the slots of four
             kernel_rate = slots * line["roofline"]["interactions_per_launch"] / (line["roofline"]["kernel_ms"] * 1e-3)
@@ -415,6 +495,8 @@ def main():
                 return mhz * 1e6 / (rate / lane_ops_per_inst / 64.0 / simds) if rate > 0 and mhz > 0 else None
 
             hk = held[args.mode]
+            if hk["held_clock_mhz"] is None:
+                hk = {"held_clock_mhz": 0.0}
             line["roofline"]["measured_issue_ceiling"] = {
                 "fma_stream_tflops": 2.0 * rates["fma"] / 1e12, "fma_stream_frac_of_spec_peak": 2.0 * rates["fma"] / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
                 "mix_stream_lane_ops_per_s": rates["mix"], "fma_stream_lane_ops_per_s": rates["fma"],

@@ -299,6 +299,16 @@ void nb_shard_destroy(nb_shard *sh);
  * (ncclCommInitRank with the id from nb_comm_id). */
 int nb_shard_use_rccl(nb_shard *sh, const void *id);
 int nb_shard_use_gather(nb_shard *sh, nb_gather_fn fn, void *user);
+/* FAST with equal ranks of whole blocks takes the pairs form on shards (nb_launch_ring_fold above: every unordered pair once, a
+ * second exchange per step) where the second exchange exists: with RCCL it is a group of ncclSend / ncclRecv; a host that brings
+ * its own all-gather (nb_shard_use_gather) brings this one too, or keeps the ordered fold.  `send`: `partners` chunks of
+ * chunk_bytes, chunk d - 1 for rank (rank + d) % world; `recv`: chunk d - 1 from rank (rank - d) % world; both device memory,
+ * `send` ready on `stream`, `recv` must be complete or ordered on `stream` on return.  nb_shard_set_pairs(sh, 0) keeps the
+ * ordered fold whatever the shape; nb_shard_pairs_partners: the D a step will use (0: the ordered fold). */
+typedef int (*nb_ring_fn)(void *user, const void *send, void *recv, size_t chunk_bytes, int partners, int rank, int world, void *stream);
+int nb_shard_use_ring(nb_shard *sh, nb_ring_fn fn, void *user);
+int nb_shard_set_pairs(nb_shard *sh, int on);
+int nb_shard_pairs_partners(const nb_shard *sh);
 /* FAST only ("Overlap"): with `on` != 0 every step folds this rank's own slot of the snapshot while the
  * exchange of the other slots is still in flight on a second stream, waits for it, then folds the rest (the two phases of
  * nb_launch_step_phase).  The order of the additions changes, which FAST may and STRICT may not: a STRICT shard (and a world

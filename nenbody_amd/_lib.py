@@ -68,6 +68,9 @@ NB_COMM_ID_BYTES = 128
 # nb_gather_fn: int (*)(void *user, void *buf, size_t slot_bytes, int rank, int world, void *stream)
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p)
 
+# nb_ring_fn: int (*)(void *user, const void *send, void *recv, size_t chunk_bytes, int partners, int rank, int world, void *stream)
+RING_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p)
+
 PROTOTYPES = {
     "nb_abi_version": (c_int, []),
     "nb_default_params": (None, [POINTER(NbParams)]),
@@ -123,6 +126,9 @@ PROTOTYPES = {
     "nb_shard_use_rccl": (c_int, [c_void_p, c_void_p]),
     "nb_shard_use_gather": (c_int, [c_void_p, GATHER_FN, c_void_p]),
     "nb_shard_set_overlap": (c_int, [c_void_p, c_int]),
+    "nb_shard_use_ring": (c_int, [c_void_p, RING_FN, c_void_p]),
+    "nb_shard_set_pairs": (c_int, [c_void_p, c_int]),
+    "nb_shard_pairs_partners": (c_int, [c_void_p]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
     "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nb_shard_step": (c_int, [c_void_p, c_uint32]),

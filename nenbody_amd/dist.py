@@ -353,12 +353,16 @@ class NativeShard:
     The same decomposition as :class:`ShardedScene` -- index ranges, one exchange of positions per step (velocities too
     for the boids controller) -- without torch: the exchange is RCCL (``comm_id`` = the bytes of :func:`comm_id`, made
     on one rank) or ``gather``, a callable ``(buf_ptr, slot_bytes, rank, world, stream_ptr) -> None`` that completes the
-    all-gather of the device buffer at ``buf_ptr``.  This is what a Rust or C++ host binds; it is wrapped here so the
-    tests can drive it.
+    all-gather of the device buffer at ``buf_ptr``.  FAST with equal ranks of whole blocks takes the pairs form (every unordered
+    pair once, ``nb_launch_ring_fold``) where its second exchange exists: RCCL's send / receive, or ``ring``, a callable
+    ``(send_ptr, recv_ptr, chunk_bytes, partners, rank, world, stream_ptr) -> None`` beside ``gather`` (chunk d - 1 of ``send``
+    goes to rank + d, chunk d - 1 of ``recv`` comes from rank - d); ``pairs=False`` keeps the ordered fold.  ``partners`` tells
+    which a step will take (0: the ordered fold).  This is what a Rust or C++ host binds; it is wrapped here so the tests can
+    drive it.
     """
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, rank: int = 0, world: int = 1,
-                 comm_id: Optional[bytes] = None, gather=None, overlap: bool = False):
+                 comm_id: Optional[bytes] = None, gather=None, overlap: bool = False, ring=None, pairs: Optional[bool] = None):
         lib = _lib.load()
         pos = np.ascontiguousarray(positions, dtype=np.float32)
         vel = np.ascontiguousarray(velocities, dtype=np.float32)
@@ -391,6 +395,22 @@ class NativeShard:
 
                 self._gather_keepalive = _lib.GATHER_FN(trampoline)
                 self._check(lib.nb_shard_use_gather(self._sh, self._gather_keepalive, None))
+            self._ring_keepalive = None
+            if ring is not None:
+                def ring_trampoline(_user, send, recv, chunk_bytes, partners, rank_, world_, stream):
+                    try:
+                        ring(send, recv, chunk_bytes, partners, rank_, world_, stream)
+                        return 0
+                    except Exception:  # pragma: no cover - reported as NB_ERR_STATE by the library
+                        import traceback
+
+                        traceback.print_exc()
+                        return 1
+
+                self._ring_keepalive = _lib.RING_FN(ring_trampoline)
+                self._check(lib.nb_shard_use_ring(self._sh, self._ring_keepalive, None))
+            if pairs is not None:
+                self._check(lib.nb_shard_set_pairs(self._sh, 1 if pairs else 0))
             if overlap:  # FAST only; a STRICT shard ignores it (nb_shard_set_overlap)
                 self._check(lib.nb_shard_set_overlap(self._sh, 1))
             self._check(lib.nb_shard_upload(self._sh, pos.ctypes.data, vel.ctypes.data))
@@ -401,6 +421,11 @@ class NativeShard:
     def _check(self, rc: int) -> None:
         if rc != _lib.NB_OK:
             raise _lib.NbError(rc, self._lib.nb_shard_last_error(self._sh).decode())
+
+    @property
+    def partners(self) -> int:
+        """D of the pairs form a step will take (``nb_shard_pairs_partners``); 0: the ordered fold and its one exchange."""
+        return int(self._lib.nb_shard_pairs_partners(self._sh))
 
     def upload(self, positions, velocities) -> None:
         """Replaces the state (all n positions, all n velocities; the rank keeps its own range of the latter)."""

@@ -46,6 +46,12 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     assert "REHEARSAL" in line["data"]
     assert line["scaling"] == "strong" and line["value"] > 0
     assert "sharding" in line["config"] and "x2" in line["config"]["sharding"]
+    # FAST on two ranks: the ordered fold with its one exchange, and the pairs form on shards with its second (point-to-point) one
+    assert line["other_mode"]["mode"] == "fast" and line["other_mode"]["roofline"]["kernel"] == "step_fast_sl_kernel"
+    pairs = line["fast_pairs_on_shards"]
+    assert pairs["partners"] == 1 and pairs["roofline"]["kernel"] == "step_fast_ring_kernel" and pairs["value"] > 0
+    assert 0 < pairs["roofline"]["frac"] < 1 and pairs["roofline"]["frac_nominal"] > pairs["roofline"]["frac"]
+    assert set(line["unpreheated"]) >= {"strict", "fast"}
 
 
 def _preheat_rank(rank, world, port, out_dir):

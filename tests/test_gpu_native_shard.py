@@ -142,7 +142,7 @@ def _hip_runtime():
     return hip
 
 
-def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None):
+def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None):
     import sys
 
     from conftest import ROOT
@@ -172,12 +172,32 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
             assert hip.hipMemcpy(buf, full.data_ptr(), world * slot_bytes, 1) == 0               # host -> device
             calls.append(slot_bytes)
 
-        pos, vel = state3d(oracle, n, seed=n)
+        ring_calls = []
+
+        def ring(send, recv, chunk_bytes, partners, rank_, world_, stream):
+            """the pairs form's second exchange through the host: chunk d - 1 of `send` to rank + d, of `recv` from rank - d"""
+            assert (rank_, world_) == (rank, world)
+            assert hip.hipStreamSynchronize(stream) == 0
+            out = torch.empty(partners * chunk_bytes, dtype=torch.uint8)
+            assert hip.hipMemcpy(out.data_ptr(), send, partners * chunk_bytes, 2) == 0
+            got = torch.empty(partners * chunk_bytes, dtype=torch.uint8)
+            ops = []
+            for d in range(1, partners + 1):
+                ops.append(dist.P2POp(dist.isend, out[(d - 1) * chunk_bytes:d * chunk_bytes], (rank + d) % world, tag=d))
+                ops.append(dist.P2POp(dist.irecv, got[(d - 1) * chunk_bytes:d * chunk_bytes], (rank - d) % world, tag=d))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            assert hip.hipMemcpy(recv, got.data_ptr(), partners * chunk_bytes, 1) == 0
+            ring_calls.append(partners)
+
+        pos, vel = state3d(oracle, n, seed=n) if seed is None else oracle.init_state(n, seed)
         with nenbody_amd.NativeShard(pos, vel, nenbody_amd.default_params(mode=mode), rank=rank, world=world,
-                                     gather=gather, overlap=overlap) as sh:
+                                     gather=gather, overlap=overlap, ring=ring if with_ring else None) as sh:
+            partners = sh.partners
             drive(sh, schedule or SCHEDULE)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sh.positions(), vel=sh.local_velocities(),
-                     inst=sh.local_instances(), first=sh.first, count=sh.count, calls=len(calls))
+                     inst=sh.local_instances(), first=sh.first, count=sh.count, calls=len(calls), ring_calls=len(ring_calls),
+                     partners=partners)
     finally:
         dist.destroy_process_group()
 
@@ -232,3 +252,31 @@ def test_fast_shards_with_overlapped_exchange(tmp_path, nb, oracle, world, n):
         assert int(got["calls"]) == 5
         covered += count
     assert covered == n
+
+
+@pytest.mark.parametrize("world,n,partners", [(2, 32768, 1), (3, 49152, 2), (4, 32768, 2)])
+def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, oracle, world, n, partners):
+    """FAST with equal ranks of whole blocks: every unordered pair once (nb_nbody_ring.inc), the other ranks' halves leaving in
+    a second exchange -- here both exchanges are the host's (gloo), the ranks are processes sharing the GPU.  Two exchanges per
+    step, results within FAST's tolerance of the oracle on every rank; without a second exchange function the same shard keeps
+    the ordered fold and its one exchange."""
+    schedule = (("nbody", 2), ("nbody", 1))
+    import torch.multiprocessing as mp
+
+    for with_ring in (True, False):
+        out = tmp_path / ("ring" if with_ring else "ordered")
+        out.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(out), False, schedule, with_ring, 77), nprocs=world, join=True)
+        pos, vel = oracle.init_state(n, 77)
+        p_ref, v_ref = reference(oracle, pos, vel, schedule)
+        for r in range(world):
+            got = np.load(os.path.join(str(out), f"rank{r}.npz"))
+            first, count = int(got["first"]), int(got["count"])
+            assert (first, count) == nb.partition(n, world)[r]
+            assert int(got["partners"]) == (partners if with_ring else 0)
+            assert int(got["calls"]) == 3 and int(got["ring_calls"]) == (3 if with_ring else 0)
+            assert np.abs(got["pos"] - p_ref).max() <= 1e-4, f"rank {r} positions (replica)"
+            assert np.abs(got["vel"] - v_ref[first:first + count]).max() <= 1e-5, f"rank {r} velocities"

@@ -46,11 +46,32 @@ class SoloScene(nb.ShardedScene):
         mine = buf[: self.slot]
         return self.dist.all_gather_into_tensor(mine, mine, async_op=async_op)
 
+    def _ring_exchange(self):
+        # the pairs form's second exchange: torch refuses a send to oneself, so the one-rank group moves the D chunks through RCCL's
+        # all-to-all instead (the same bytes through the same library; the native path below does send to itself)
+        self.dist.all_to_all_single(self.recv, self.sums[self.count:])
 
-def python_path(mode, exchange=True, overlap=False):
-    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0, overlap=overlap)
+
+def python_path(mode, exchange=True, overlap=False, ring=False):
+    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0, overlap=overlap, ring=ring)
     if not exchange:
         sc._all_gather_slots = lambda buf, async_op=False: None
+        sc._ring_exchange = lambda: None
+    if ring:  # two launch calls per step: device time = events around the whole loop with the exchanges off
+        assert sc.partners
+        for _ in range(10):
+            sc.step()
+        sc.sync()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            sc.step()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        return wall, e0.elapsed_time(e1) / steps * 1e-3
     for _ in range(10):
         sc.step()
     sc.sync()
@@ -86,9 +107,10 @@ def python_path(mode, exchange=True, overlap=False):
     return wall, dev
 
 
-def native_path(mode, overlap=False):
+def native_path(mode, overlap=False, pairs=False):
     nb.load().nb_diag_rccl_solo(1)   # a communicator of one rank whatever `world` is (include/nenbody_diag.h)
-    sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id(), overlap=overlap)
+    sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id(), overlap=overlap, pairs=pairs)
+    assert bool(sh.partners) == pairs
     sh.step(10)
     sh.sync()
     t0 = time.perf_counter()
@@ -102,7 +124,7 @@ def native_path(mode, overlap=False):
 
 print(f"rank 0's share: {count} of {n} bodies (world {world}), {steps} steps; exchange = RCCL all-gather on a one-rank communicator")
 for name, mode in (("STRICT", nb.NB_MODE_STRICT), ("FAST", nb.NB_MODE_FAST)):
-    w_noex, dev = python_path(mode, exchange=False)
+    w_noex, dev = python_path(mode, exchange=False)   # (ring=False: the ordered fold and its one exchange)
     w_py, dev2 = python_path(mode)
     w_c = native_path(mode)
     print(f"{name:6s} dev/step {dev * 1e6:8.1f} us (with the exchange between steps: {dev2 * 1e6:8.1f})", flush=True)
@@ -116,4 +138,12 @@ for name, mode in (("STRICT", nb.NB_MODE_STRICT), ("FAST", nb.NB_MODE_FAST)):
         w_cov = native_path(mode, overlap=True)
         print(f"{name:6s} ShardedScene, overlapped  : wall/step {w_ov * 1e6:8.1f} us  ({(w_ov - w_py) * 1e6:+.1f} us against the plain step)", flush=True)
         print(f"{name:6s} NativeShard,  overlapped  : wall/step {w_cov * 1e6:8.1f} us  ({(w_cov - w_c) * 1e6:+.1f} us against the plain step)", flush=True)
+        # the pairs form on shards: fold, second exchange, finish, all-gather
+        w_rn, dev_r = python_path(mode, exchange=False, ring=True)
+        w_r, _ = python_path(mode, ring=True)
+        w_cr = native_path(mode, pairs=True)
+        print(f"{name:6s} pairs form on shards: dev/step {dev_r * 1e6:8.1f} us (events around the loop, exchanges off)", flush=True)
+        print(f"{name:6s} ShardedScene pairs form, no exchange      : wall/step {w_rn * 1e6:8.1f} us", flush=True)
+        print(f"{name:6s} ShardedScene pairs form + both exchanges  : wall/step {w_r * 1e6:8.1f} us  (+{(w_r - w_rn) * 1e6:.1f} us)", flush=True)
+        print(f"{name:6s} NativeShard  pairs form + both exchanges  : wall/step {w_cr * 1e6:8.1f} us  (+{(w_cr - w_rn) * 1e6:.1f} us)", flush=True)
 dist.destroy_process_group()
