@@ -44,7 +44,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -87,6 +87,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_pairs_w = read_knob("NB_FAST_PAIRS_W");
     d->fast_pairs_chunk = read_knob("NB_FAST_PAIRS_CHUNK");
     d->fast_pairs_np = read_knob("NB_FAST_PAIRS_NP");
+    d->inst_device_libm = read_knob("NB_INST_DEVICE_LIBM");
     d->ring = read_knob("NB_RING");
     d->ring_np = read_knob("NB_RING_NP");
     d->ring_ga = read_knob("NB_RING_GA");
@@ -1098,7 +1099,7 @@ NB_EXPORT int nb_device_state(nb_ctx *ctx, const void **pos_rec, const void **ve
     }
     if (inst_16n) {
         if (!ctx->inst) NB_HIP(ctx, hipMalloc((void **)&ctx->inst, (size_t)ctx->n * 16 * sizeof(float)));
-        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream));
+        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream, overrides().inst_device_libm.on() ? 1u : 0u));
         *inst_16n = ctx->inst;
     }
     if (pos_rec) *pos_rec = ctx->pos[ctx->cur];
@@ -1193,7 +1194,8 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         const bool with_status = ctx->status.dirty && ctx->status.w;
         NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)dst : nullptr,
                                        pos_xyz ? dst + 16 * n : nullptr, vel_xyz ? dst + 19 * n : nullptr,
-                                       with_status ? ctx->status.w : nullptr, with_status ? (uint32_t *)(dst + 22 * n) : nullptr, ctx->stream));
+                                       with_status ? ctx->status.w : nullptr, with_status ? (uint32_t *)(dst + 22 * n) : nullptr, ctx->stream,
+                                       overrides().inst_device_libm.on() ? 1u : 0u));
         if (!zero_copy) {
             const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = with_status ? 22 * n + 1 : vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
             NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1216,7 +1218,7 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
     }
     if (inst_16n) {
         if (!ctx->inst) NB_HIP(ctx, hipMalloc((void **)&ctx->inst, (size_t)ctx->n * 16 * sizeof(float)));
-        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream));
+        NB_HIP(ctx, nbk::launch_instances(ctx->n, ctx->pos[ctx->cur], ctx->vel, ctx->inst, ctx->stream, overrides().inst_device_libm.on() ? 1u : 0u));
         NB_HIP(ctx, hipMemcpyAsync(inst_16n, ctx->inst, (size_t)ctx->n * 16 * sizeof(float), hipMemcpyDeviceToHost,
                                    ctx->stream));
         NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1315,7 +1317,7 @@ int update_roundtrip(nb_ctx *c, int kind, const nb_boids_params *bp, const float
     // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait per frame
     const bool with_status = c->status.dirty && c->status.w;
     NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, with_status ? c->status.w : nullptr,
-                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream));
+                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream, overrides().inst_device_libm.on() ? 1u : 0u));
     if (!zero_copy)
         NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     NB_HIP(c, hipStreamSynchronize(c->stream));
@@ -2352,7 +2354,7 @@ NB_EXPORT int nb_launch_instances(uint32_t count, const void *pos, const void *v
         g_tls_error = "nb_launch_instances: bad argument";
         return NB_ERR_INVALID;
     }
-    NB_LAUNCH_TLS(nbk::launch_instances(count, (const float4 *)pos, (const float4 *)vel, (float4 *)inst_16n, (hipStream_t)stream));
+    NB_LAUNCH_TLS(nbk::launch_instances(count, (const float4 *)pos, (const float4 *)vel, (float4 *)inst_16n, (hipStream_t)stream, overrides().inst_device_libm.on() ? 1u : 0u));
 }
 
 NB_EXPORT int nb_launch_cameras(uint32_t count, const void *eyes, const void *dirs, const float *up_xyz, const float *cp16,

@@ -105,7 +105,8 @@ hipError_t launch_fast_ring_kernels(const StepArgs &a, uint32_t np, uint32_t ga,
 hipError_t launch_ring_finish(const StepArgs &a, const float4 *sums, const float4 *recv, uint32_t partners, hipStream_t s);
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
-hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s);
+// device_libm: 0 = the angle, its sine and cosine as the host's libm computes them (nb_libm.h: bit-identical matrices), 1 = the device's own
+hipError_t launch_instances(uint32_t count, const float4 *pos, const float4 *vel, float4 *inst, hipStream_t s, uint32_t device_libm = 0);
 hipError_t launch_cameras(uint32_t count, const float4 *eyes, const float4 *dirs, const float *up3, const float *cp16, float4 *out,
                           hipStream_t s);
 hipError_t launch_random(uint32_t first, uint32_t count, float4 *pos, float4 *vel, uint64_t seed, uint64_t step, hipStream_t s);
@@ -127,6 +128,6 @@ hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStrea
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each
 hipError_t launch_import(uint32_t count, const float *pos_xyz, const float *vel_xyz, float4 *pos_rec, float4 *vel_rec, hipStream_t s);
 hipError_t launch_export(uint32_t count, const float4 *pos_rec, const float4 *vel_rec, float4 *inst, float *pos_xyz, float *vel_xyz,
-                         const uint32_t *status_src, uint32_t *status_dst, hipStream_t s);
+                         const uint32_t *status_src, uint32_t *status_dst, hipStream_t s, uint32_t device_libm = 0);
 
 }  // namespace nbk

@@ -9,6 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def matrices_equal(got, ref):
+    """model matrices (main.rs:437-439) word for word: since round 4 the device computes the angle, its sine and cosine as the host's
+    libm does (nenbody_amd/csrc/nb_libm.h); NaN entries (non-finite velocities) compare equal whatever their payload"""
+    g, r = np.ascontiguousarray(got, np.float32), np.ascontiguousarray(ref, np.float32)
+    return g.shape == r.shape and bool(((g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))).all())
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -107,7 +114,7 @@ def test_boids_reference_initial_state_long_run(nb, oracle):
     p_ref, v_ref, inst_ref = oracle.boids_run(pos, vel, 100, want_instances=True)
     assert_bits_equal(p, p_ref)
     assert_bits_equal(v, v_ref)
-    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    assert matrices_equal(inst, inst_ref)
     assert (p[:, 2] == 0).all()
 
 
@@ -286,7 +293,7 @@ def test_update_instance_boids_operator(nb, oracle):
     assert_bits_equal(old_v, vel)            # main.rs:460
     assert_bits_equal(positions, p_ref)
     assert_bits_equal(velocities, v_ref)
-    assert np.allclose(inst, inst_ref, rtol=0, atol=1e-6)
+    assert matrices_equal(inst, inst_ref)
     with pytest.raises(ValueError):
         nb.update_instance_boids(inst, positions, np.zeros((n - 1, 3), np.float32), velocities, old_v)
 
@@ -359,7 +366,7 @@ def test_update_instance_boids_slices_of_unequal_length(nb, oracle, n_inst, n_po
     assert_bits_equal(positions[m:], pos[m:], "bodies past the zip keep their positions")
     assert_bits_equal(velocities[m:], vel[m:], "bodies past the zip keep their velocities")
     assert np.abs(inst[:m, 3, :3] - p_ref).max() == 0.0
-    np.testing.assert_allclose(inst[:m], i_ref, atol=1e-6, rtol=0)
+    assert matrices_equal(inst[:m], i_ref)
     assert not inst[m:].any()
 
 

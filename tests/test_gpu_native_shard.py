@@ -12,6 +12,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def matrices_equal(got, ref):
+    """model matrices (main.rs:437-439) word for word: since round 4 the device computes the angle, its sine and cosine as the host's
+    libm does (nenbody_amd/csrc/nb_libm.h); NaN entries (non-finite velocities) compare equal whatever their payload"""
+    g, r = np.ascontiguousarray(got, np.float32), np.ascontiguousarray(ref, np.float32)
+    return g.shape == r.shape and bool(((g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))).all())
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -55,7 +62,7 @@ def test_world_of_one_needs_no_exchange(nb, oracle, n):
     p_ref, v_ref = reference(oracle, pos, vel, SCHEDULE)
     assert_bits_equal(p, p_ref, "positions")
     assert_bits_equal(v, v_ref, "velocities")
-    assert np.allclose(inst, oracle.instances(p_ref, v_ref), rtol=0, atol=1e-6)
+    assert matrices_equal(inst, oracle.instances(p_ref, v_ref))
 
 
 def test_rccl_world_of_one(nb, oracle):
@@ -220,7 +227,7 @@ def test_worlds_of_two_and_three_equal_the_oracle(tmp_path, nb, oracle, world, n
         assert (first, count) == nb.partition(n, world)[r]
         assert_bits_equal(got["pos"], p_ref, f"rank {r} positions (replica)")
         assert_bits_equal(got["vel"], v_ref[first:first + count], f"rank {r} velocities")
-        assert np.allclose(got["inst"], inst_ref[first:first + count], rtol=0, atol=1e-6)
+        assert matrices_equal(got["inst"], inst_ref[first:first + count])
         # n-body: one exchange per step; boids: ONE per step too (positions and velocities travel in one staging buffer),
         # + one rebuild of the velocity replica each time boids follows n-body steps
         assert int(got["calls"]) == 3 + (1 + 2) + (1 + 1)

@@ -153,3 +153,68 @@ def test_device_state_handoff(nb, oracle):
     p_ref, v_ref = oracle.run(pos, vel, 2)
     assert (bits(p) == bits(p_ref)).all()
     del torch
+
+
+def test_model_matrices_are_bit_identical(nb, oracle, monkeypatch):
+    """Row a7 (src/main.rs:437-439, rotation_of :141-143) word for word: M = T(p) * Rz(atan2(v.y, v.x)) with the angle, its sine
+    and its cosine computed on the device as the HOST's libm computes them (nenbody_amd/csrc/nb_libm.h: glibc's atan2f / sinf /
+    cosf restated; the oracle calls the host libm itself, as the reference's f32::atan2 / sin_cos do).  A million drawn velocities
+    -- the step's own range, every binade from 2^-60 to 2^60 in either component, near-axis and near-diagonal directions -- and the
+    edge cases: signed zeros, subnormals, the axes, infinities, NaN, x = 1 exactly (atan2f's shortcut), ratios at atanf's interval
+    boundaries.  The device's own libm (NB_INST_DEVICE_LIBM=1, the form until round 3) stays within 1e-6 and differs in the last
+    place somewhere: the control arm."""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    rng = np.random.default_rng(2024)
+    m = 1 << 20
+    vel = np.zeros((m, 3), np.float32)
+    q = m // 4
+    vel[:q, :2] = rng.uniform(-0.2, 0.2, (q, 2))                                          # what a step produces
+    e = rng.integers(-60, 61, (q, 2))
+    vel[q:2 * q, :2] = (rng.uniform(1, 2, (q, 2)) * np.exp2(e) * rng.choice([-1, 1], (q, 2))).astype(np.float32)   # every binade
+    ang = rng.uniform(-np.pi, np.pi, q)
+    r = np.exp2(rng.uniform(-20, 20, q))
+    vel[2 * q:3 * q, 0], vel[2 * q:3 * q, 1] = (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
+    k = np.arange(q)                                                                        # near the axes and the diagonals
+    base = np.array([[1, 0], [0, 1], [-1, 0], [0, -1], [1, 1], [-1, 1], [1, -1], [-1, -1]], np.float32)[k % 8]
+    vel[3 * q:, :2] = base + rng.uniform(-1, 1, (q, 2)).astype(np.float32) * np.exp2(rng.integers(-30, -1, (q, 1))).astype(np.float32)
+    sub, big, inf, nan = np.float32(1e-42), np.float32(3e38), np.float32(np.inf), np.float32(np.nan)
+    edge = [(0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 0.0), (0.0, 1.0), (-1.0, 0.0), (0.0, -1.0), (sub, sub), (-sub, sub),
+            (sub, 1.0), (1.0, sub), (big, big), (-big, big), (big, -sub), (inf, 1.0), (1.0, inf), (-inf, inf), (inf, -inf), (nan, 1.0),
+            (1.0, nan), (1.0, 0.4375), (1.0, 0.6875), (1.0, 1.1875), (1.0, 2.4375), (1.0, 2.0 ** 25), (1.0, 2.0 ** -29), (2.0, 0.875),
+            (-3.0, 7.3125), (1.0, 1.0), (-1.0, -1.0), (0.5, 2.0 ** 61), (-0.5, 2.0 ** -61), (-2.0 ** 61, 0.5)]
+    vel[:len(edge), 0] = [a for a, _ in edge]
+    vel[:len(edge), 1] = [b for _, b in edge]
+    pos = rng.uniform(-100, 100, (m, 3)).astype(np.float32)
+    pos[:8] = [[0, 0, 0], [-0.0, -0.0, -0.0], [inf, 1, 2], [nan, 1, 2], [1e-40, -1e-40, 3], [3e38, -3e38, 1], [1, 2, 3], [-1, -2, -3]]
+    ref = oracle.instances(pos, vel)
+    be, dev = HipBackend(), torch.device("cuda", 0)
+
+    def rec(a):
+        t = torch.zeros((m, 4))
+        t[:, :3] = torch.from_numpy(a)
+        return t.to(dev)
+
+    def device_matrices():
+        inst = torch.zeros((m, 16), device=dev)
+        be.instances(m, rec(pos), rec(vel), inst)
+        torch.cuda.synchronize()
+        return inst.cpu().numpy().reshape(m, 4, 4)
+
+    got = device_matrices()
+    same = (bits(got) == bits(ref)) | (np.isnan(got) & np.isnan(ref))
+    bad = np.argwhere(~same.reshape(m, 16).all(axis=1)).ravel()
+    assert len(bad) == 0, f"{len(bad)} of {m} matrices differ; first: velocity {vel[bad[0]]!r}: {got[bad[0]].ravel()!r} vs {ref[bad[0]].ravel()!r}"
+    # the context API and the drop-in call produce them through the same device function
+    with nb.Scene(pos[:4096], vel[:4096]) as sc:
+        assert (((bits(sc.instances()) == bits(ref[:4096])) | np.isnan(ref[:4096])).all())
+    # control arm: the device's own atan2f / sinf / cosf
+    monkeypatch.setenv("NB_INST_DEVICE_LIBM", "1")
+    old = device_matrices()
+    finite = np.isfinite(ref).all(axis=(1, 2)) & np.isfinite(old).all(axis=(1, 2))
+    assert np.abs(old[finite] - ref[finite])[:, :2, :2].max() <= 1e-6
+    differing = int((bits(old[finite]) != bits(ref[finite])).any(axis=(1, 2)).sum())
+    print(f"device libm: {differing} of {int(finite.sum())} matrices differ from the host's in some word")
+    assert differing > 0
