@@ -65,8 +65,8 @@ def committed_traffic(nb, kernels, n, count):
         t = json.load(open(path))
     except Exception as e:
         return None, f"no usable profiles/hbm_traffic.json ({e.__class__.__name__})"
-    if t.get("src_sha") != nb._lib.kernel_source_sha():
-        return None, "profiles/hbm_traffic.json was measured on other kernel sources (src_sha differs): stale, not reported"
+    if t.get("code_sha") != nb._lib.kernel_code_sha():
+        return None, "profiles/hbm_traffic.json was measured on other device code (code_sha differs from the built library's): stale, not reported"
     if t.get("n") != n or t.get("count") != count:
         return None, "profiles/hbm_traffic.json is for another shape"
     missing = [k for k in kernels if k not in t.get("kernels", {})]

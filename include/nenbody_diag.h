@@ -40,8 +40,9 @@ int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
  * workgroup's first wave at entry and exit.  bench.py prints them beside the spec peak its roofline fraction is quoted against. */
 int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s, double *clock_mhz);
 
-/* Diagnostic: the shader clock the part holds under the whole-set step kernel of `params` (STRICT: step_strict_kernel, one
- * lane per body; FAST: step_fast_wave_kernel) on n bodies of the reference's initial distribution (seed 1234): back-to-back
+/* Diagnostic: the shader clock the part holds under the whole-set step kernel of `params` (STRICT: step_strict_sl_kernel, one
+ * lane per body through scalar loads; FAST: step_fast_pairs_kernel, or step_fast_sl_kernel where the plan takes the ordered
+ * fold) on n bodies of the reference's initial distribution (seed 1234): back-to-back
  * steps for about `seconds` (<= 5), the last of them with the kernel's diagnostic stamps switched on (StepArgs::stamps: the
  * first wave of every workgroup stores s_memtime and s_memrealtime at entry and exit; no output depends on them).
  * clock_mhz: median over workgroups; wave_cycles (may be NULL): median lifetime of those waves in shader cycles; kernel_ms
@@ -49,12 +50,16 @@ int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s, doubl
 int nb_diag_step_clock(const nb_params *params, uint32_t n, double seconds, double *clock_mhz, double *wave_cycles,
                        double *kernel_ms);
 
-/* Diagnostic: the NB_* environment variables (kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
- * NB_FAST_GROUPS, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _NO_PACKED / _FORCE_IEEE,
- * NB_BC_SPIN_BUDGET, NB_BOIDS_PC / _TILE / _FORCE, NB_SELFTEST_CONTROL, NB_DROPIN_ZERO_COPY, and NB_ROCTX = 1: roctx ranges
- * around the step loops and the exchange, for rocprofv3 --marker-trace) are read ONCE per process, at first use; no launch
- * path reads the environment.  A test or tool that changes them afterwards calls this to have them read again.  Contexts
- * and shards keep the launch shape chosen when they were created. */
+/* Diagnostic: the NB_* environment variables -- kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
+ * NB_FAST_GROUPS, NB_FAST_WAVES, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FAST_SL, NB_FAST_PAIRS / _W / _NP / _CHUNK, NB_RING / _NP / _GA /
+ * _WPB, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _SL / _NO_PACKED / _FORCE_IEEE, NB_BC_SPIN_BUDGET, NB_BC_PRIO,
+ * NB_BOIDS_PC / _TILE / _FORCE, NB_INST_DEVICE_LIBM, NB_SELFTEST_CONTROL, NB_DROPIN_ZERO_COPY -- are NOT read by a process that
+ * merely loads the library: nothing a deployment's environment exports steers which kernels run.  nb_diag_enable_env(1) has
+ * them read (now, and again at every nb_debug_reload_env()); nb_diag_enable_env(0) forgets them.  nb_debug_reload_env() alone
+ * also switches the reading on (a test or tool that has just changed one calls it).  No launch path reads the environment;
+ * contexts and shards keep the launch shape chosen when they were created.  (NB_ROCTX = 1 -- roctx ranges around the step
+ * loops and the exchanges, for rocprofv3 --marker-trace -- is a feature for hosts, not a kernel form, and is always read.) */
+int nb_diag_enable_env(int on);
 int nb_debug_reload_env(void);
 
 /* Test-only: with on != 0, nb_shard_use_rccl builds a communicator of ONE rank whatever the shard's world is, and the

@@ -29,8 +29,20 @@ inline void check(int rc, const nb_ctx *ctx)
     if (rc != NB_OK) throw Error(rc, nb_last_error(ctx));
 }
 
+// The library that got loaded must speak the ABI this header was written against: a symbol may keep its name and change its
+// arguments between versions (nb_update_instance_random: eight in ABI 1, six since ABI 2), and the linker cannot tell.  Checked
+// once per process, by every entry point of this header, before anything else crosses the boundary.
+inline void check_abi()
+{
+    static const int got = nb_abi_version();
+    if (got != NB_ABI_VERSION)
+        throw Error(NB_ERR_UNSUPPORTED, "libnenbody_hip.so speaks ABI " + std::to_string(got) + ", this host was built against ABI " +
+                                            std::to_string(NB_ABI_VERSION));
+}
+
 inline nb_params default_params(uint32_t mode = NB_MODE_STRICT)
 {
+    check_abi();
     nb_params p;
     nb_default_params(&p);  // src/main.rs:411-413
     p.mode = mode;
@@ -82,6 +94,7 @@ public:
 private:
     void create(const nb_params &params)
     {
+        check_abi();
         if (positions.empty()) throw std::invalid_argument("a Scene needs at least one body");
         check(nb_create((uint32_t)positions.size(), 1, &params, &ctx_), nullptr);
         int rc = nb_upload(ctx_, positions[0].data(), velocities[0].data());
@@ -107,8 +120,10 @@ public:
         return id;
     }
     Shard(const std::vector<Vec3> &positions, const std::vector<Vec3> &velocities, int rank, int world, const nb_params &params,
-          const void *rccl_id = nullptr, nb_gather_fn gather = nullptr, void *gather_user = nullptr)
+          const void *rccl_id = nullptr, nb_gather_fn gather = nullptr, void *gather_user = nullptr, nb_ring_fn ring = nullptr,
+          void *ring_user = nullptr)
     {
+        check_abi();
         if (positions.empty() || positions.size() != velocities.size())
             throw std::invalid_argument("positions and velocities must be non-empty and equally long");
         check(nb_shard_create((uint32_t)positions.size(), rank, world, &params, &sh_), nullptr);
@@ -117,6 +132,9 @@ public:
             check_sh(nb_shard_range(sh_, &first_, &count_));
             if (rccl_id) check_sh(nb_shard_use_rccl(sh_, rccl_id));
             else if (gather) check_sh(nb_shard_use_gather(sh_, gather, gather_user));
+            // FAST on equal ranks: every unordered pair once, with a second exchange per step (include/nenbody.h); RCCL brings
+            // it along, a host exchange needs `ring` beside `gather` (else the ordered fold stays)
+            if (ring) check_sh(nb_shard_use_ring(sh_, ring, ring_user));
             check_sh(nb_shard_upload(sh_, positions[0].data(), velocities[0].data()));
         } catch (...) {
             nb_shard_destroy(sh_);
@@ -129,6 +147,7 @@ public:
 
     uint32_t first() const { return first_; }
     uint32_t count() const { return count_; }
+    int pairs_partners() const { return nb_shard_pairs_partners(sh_); }  // D of the pairs form a step will take; 0: the ordered fold
     void step(uint32_t k = 1) { check_sh(nb_shard_step(sh_, k)); }
     void step_boids(uint32_t k = 1, const nb_boids_params *params = nullptr) { check_sh(nb_shard_step_boids(sh_, k, params)); }
     // FAST only (a STRICT shard ignores it): fold the rank's own slot while the exchange of the others is in flight
@@ -171,6 +190,7 @@ inline void update_instance_nbody(std::vector<Mat4> &instances, std::vector<Vec3
                                   std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities,
                                   const nb_params *params = nullptr)
 {
+    check_abi();
     detail::update_status(nb_update_instance_nbody(detail::ptr(instances), instances.size(), detail::ptr(positions),
                                                    positions.size(), detail::ptr(old_positions), old_positions.size(),
                                                    detail::ptr(velocities), velocities.size(), detail::ptr(old_velocities),
@@ -181,6 +201,7 @@ inline void update_instance_boids(std::vector<Mat4> &instances, std::vector<Vec3
                                   std::vector<Vec3> &velocities, std::vector<Vec3> &old_velocities,
                                   const nb_boids_params *params = nullptr)
 {
+    check_abi();
     detail::update_status(nb_update_instance_boids(detail::ptr(instances), instances.size(), detail::ptr(positions),
                                                    positions.size(), detail::ptr(old_positions), old_positions.size(),
                                                    detail::ptr(velocities), velocities.size(), detail::ptr(old_velocities),
@@ -191,6 +212,7 @@ inline void update_instance_boids(std::vector<Mat4> &instances, std::vector<Vec3
 // arguments; the library keeps the seed and counts the calls (nb_update_random_seed restarts the stream)
 inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &velocities)
 {
+    check_abi();
     detail::update_status(nb_update_instance_random(detail::ptr(instances), instances.size(), detail::ptr(positions), positions.size(),
                                                     detail::ptr(velocities), velocities.size()));
 }
@@ -199,6 +221,7 @@ inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec
 inline void update_instance_random(std::vector<Mat4> &instances, std::vector<Vec3> &positions, std::vector<Vec3> &velocities,
                                    uint64_t seed, uint64_t step)
 {
+    check_abi();
     detail::update_status(nb_update_instance_random_seeded(detail::ptr(instances), instances.size(), detail::ptr(positions),
                                                            positions.size(), detail::ptr(velocities), velocities.size(), seed, step));
 }

@@ -38,8 +38,14 @@ pub struct NbCtx {
     _private: [u8; 0],
 }
 
+/// The ABI this binding was written against (include/nenbody.h: NB_ABI_VERSION).  A symbol may keep its name and change its
+/// arguments between versions (`nb_update_instance_random`: eight in ABI 1, six since ABI 2) and the linker cannot tell, so
+/// every entry point of this module checks it once per process before anything else crosses the boundary.
+pub const NB_ABI_VERSION: c_int = 2;
+
 #[link(name = "nenbody_hip")]
 extern "C" {
+    fn nb_abi_version() -> c_int;
     fn nb_default_params(p: *mut NbParams);
     fn nb_last_error(ctx: *const NbCtx) -> *const c_char;
     fn nb_init_state(seed: u64, n: u32, pos_xyz: *mut f32, vel_xyz: *mut f32) -> c_int;
@@ -72,8 +78,17 @@ extern "C" {
     fn nb_update_random_seed(seed: u64);
 }
 
+fn check_abi() {
+    static ONCE: std::sync::Once = std::sync::Once::new();
+    ONCE.call_once(|| {
+        let got = unsafe { nb_abi_version() };
+        assert_eq!(got, NB_ABI_VERSION, "libnenbody_hip.so speaks ABI {}, this binding was written against ABI {}", got, NB_ABI_VERSION);
+    });
+}
+
 impl Default for NbParams {
     fn default() -> Self {
+        check_abi();
         let mut p = NbParams { dt: 0.0, g: 0.0, bias: 0.0, tile: 0, mode: 0 };
         unsafe { nb_default_params(&mut p) };
         p
@@ -105,6 +120,7 @@ unsafe impl Send for Scene {}
 impl Scene {
     /// `entity_count` bodies with the reference's initial distributions (src/main.rs:738-747), seeded.
     pub fn new(n: usize, params: NbParams, seed: u64) -> Result<Scene, SceneError> {
+        check_abi();
         let mut positions = vec![Point3::new(0.0f32, 0.0, 0.0); n];
         let mut velocities = vec![Vector3::new(0.0f32, 0.0, 0.0); n];
         // Point3<f32> / Vector3<f32> are #[repr(C)] {x, y, z}: the Vec's buffer is the stride-3 array the ABI takes
@@ -116,6 +132,7 @@ impl Scene {
     }
 
     pub fn from_state(positions: Vec<Point3<f32>>, velocities: Vec<Vector3<f32>>, params: NbParams) -> Result<Scene, SceneError> {
+        check_abi();
         // same panic the reference has at src/main.rs:415-416 (copy_from_slice on unequal lengths)
         assert_eq!(positions.len(), velocities.len(), "positions and velocities must have the same length");
         let n = positions.len();
@@ -189,6 +206,7 @@ pub fn update_instance_nbody(
     velocities: &mut Vec<Vector3<f32>>,
     old_velocities: &mut Vec<Vector3<f32>>,
 ) {
+    check_abi();
     let rc = unsafe {
         nb_update_instance_nbody(
             instances.as_mut_ptr() as *mut f32, instances.len(),
@@ -212,6 +230,7 @@ pub fn update_instance_boids(
     velocities: &mut Vec<Vector3<f32>>,
     old_velocities: &mut Vec<Vector3<f32>>,
 ) {
+    check_abi();
     let rc = unsafe {
         nb_update_instance_boids(
             instances.as_mut_ptr() as *mut f32, instances.len(),
@@ -235,6 +254,7 @@ pub fn update_instance_random(
     positions: &mut Vec<Point3<f32>>,
     velocities: &mut Vec<Vector3<f32>>,
 ) {
+    check_abi();
     let rc = unsafe {
         nb_update_instance_random(
             instances.as_mut_ptr() as *mut f32, instances.len(),
@@ -255,6 +275,7 @@ pub fn update_instance_random_seeded(
     seed: u64,
     step: u64,
 ) {
+    check_abi();
     let rc = unsafe {
         nb_update_instance_random_seeded(
             instances.as_mut_ptr() as *mut f32, instances.len(),

@@ -147,6 +147,7 @@ DIAG_PROTOTYPES = {
     "nb_diag_step_clock": (c_int, [POINTER(NbParams), c_uint32, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double)]),
     "nb_debug_reload_env": (c_int, []),
+    "nb_diag_enable_env": (c_int, [c_int]),
     "nb_diag_rccl_solo": (c_int, [c_int]),
     "nb_diag_plan": (c_int, [POINTER(NbParams), c_uint32, c_uint32, ctypes.c_char_p, c_size_t]),
 }
@@ -221,6 +222,46 @@ def kernel_source_sha() -> str:
     for name in sorted(BENCHED_KERNEL_SOURCES):
         h.update(name.encode())
         h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def kernel_code_sha(path: str = None) -> str:
+    """sha256 (first 16 hex digits) of the DEVICE CODE of the benchmarked kernels as built into the library: the offload bundles of
+    its `.hip_fatbin` section that hold the whole-set folds (the scalar-load unit: step_strict_sl_kernel, the pairs forms) and
+    planes_kernel / the combines (the main unit) -- not the boids unit.  This is what stamps profiles/hbm_traffic.json since
+    round 4: a comment, a test, a host-side or a boids edit leaves the measured kernels' code -- and so the evidence -- as it was,
+    where the source-text hash above made every comment-only commit cost a rocprofv3 + PMC re-collection.
+    The bundles carry no line numbers or paths: the same sources and compiler give the same bytes."""
+    import hashlib
+    import struct
+
+    b = open(path or LIB_PATH, "rb").read()
+    if b[:4] != b"\x7fELF":
+        raise ValueError("not an ELF file")
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+    stroff = secs[shstrndx][4]
+    fat = None
+    for sec in secs:
+        name = b[stroff + sec[0]:b.index(b"\0", stroff + sec[0])]
+        if name == b".hip_fatbin":
+            fat = b[sec[4]:sec[4] + sec[5]]
+    if fat is None:
+        raise ValueError("no .hip_fatbin section")
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts, i = [], fat.find(magic)
+    while i >= 0:
+        starts.append(i)
+        i = fat.find(magic, i + 1)
+    h, used = hashlib.sha256(), 0
+    for a, e in zip(starts, starts[1:] + [len(fat)]):
+        bundle = fat[a:e]
+        if b"step_strict_sl_kernel" in bundle or b"planes_kernel" in bundle:
+            h.update(bundle)
+            used += 1
+    if used != 2:
+        raise ValueError(f"expected the main and the scalar-load bundle in .hip_fatbin, found {used} of {len(starts)}")
     return h.hexdigest()[:16]
 
 

@@ -346,19 +346,52 @@ def test_diagnostic_entry_points_validate_and_refuse_without_a_device(nb):
         nb.update_instance_boids(np.zeros((12, 4, 4), np.float32), pos[:5].copy(), pos[:5].copy(), vel, vel.copy())
 
 
+def test_the_evidence_stamp_is_of_the_device_code_not_of_the_source_text(nb, tmp_path):
+    """kernel_code_sha hashes the offload bundles of the benchmarked kernels inside the built library: it is
+    a function of the library file alone, stable from call to call, blind to everything outside `.hip_fatbin` (a copy of the
+    library with its host code patched hashes the same) and to the boids unit's bundle, and it moves when a byte of a hashed
+    bundle does."""
+    from nenbody_amd import _lib
+
+    a = _lib.kernel_code_sha()
+    assert len(a) == 16 and a == _lib.kernel_code_sha()
+    blob = bytearray(open(_lib.LIB_PATH, "rb").read())
+    i = blob.find(b"nb_launch_ring_fold: pos_in, sums and scratch must be non-null")     # a host-side string
+    assert i > 0
+    blob[i:i + 2] = b"NB"
+    host_patched = tmp_path / "host.so"
+    host_patched.write_bytes(blob)
+    assert _lib.kernel_code_sha(str(host_patched)) == a
+    blob = bytearray(open(_lib.LIB_PATH, "rb").read())
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts, j = [], blob.find(magic)
+    while j >= 0:
+        starts.append(j)
+        j = blob.find(magic, j + 1)
+    assert len(starts) == 3
+    for k, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        patched = bytearray(blob)
+        mid = lo + (min(hi, lo + 600000) - lo) // 2
+        patched[mid] ^= 0xFF
+        f = tmp_path / f"bundle{k}.so"
+        f.write_bytes(patched)
+        hashed = b"step_strict_sl_kernel" in blob[lo:hi] or b"planes_kernel" in blob[lo:hi]
+        assert (_lib.kernel_code_sha(str(f)) != a) == hashed, f"bundle {k}"
+
+
 def test_committed_hbm_traffic_is_of_the_current_kernel_sources(nb):
-    """bench.py reports roofline.traffic from profiles/hbm_traffic.json only when the file's stamp is the sha of the kernel
-    sources that are running (tools/pmc_summary.py --json writes both).  A kernel edit without a new rocprofv3 --pmc run
-    leaves the file stale -- bench.py then reports traffic = null with the reason; this test makes that visible here."""
+    """bench.py reports roofline.traffic from profiles/hbm_traffic.json only when the file's stamp is the hash of the device code
+    that is running (tools/pmc_summary.py --json writes it).  A kernel change without a new rocprofv3 --pmc run leaves the file
+    stale -- bench.py then reports traffic = null with the reason; this test makes that visible here."""
     import json
 
     from nenbody_amd import _lib
 
     t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-    assert set(t) >= {"n", "count", "src_sha", "kernels", "source"} and t["n"] == 131072 and t["count"] == 131072
-    if t["src_sha"] != _lib.kernel_source_sha():
-        pytest.skip("profiles/hbm_traffic.json is stale (kernel sources changed since the PMC passes): re-run tools/profile_bench.sh "
-                    "and tools/pmc_summary.py --json")
+    assert set(t) >= {"n", "count", "kernels", "source"} and t["n"] == 131072 and t["count"] == 131072
+    if t.get("code_sha") != _lib.kernel_code_sha():
+        pytest.skip("profiles/hbm_traffic.json is stale (the device code of the benchmarked kernels changed since the PMC passes): "
+                    "re-run tools/profile_bench.sh and tools/collect_profiles.sh")
     # every kernel the two arithmetics launch per step at this shape, as the library plans it
     planned = set(_lib.planned_kernels(nb.default_params(), 131072, 131072)) | set(_lib.planned_kernels(nb.default_params(mode=nb.NB_MODE_FAST), 131072, 131072))
     assert planned >= {"step_strict_sl_kernel", "step_fast_pairs_kernel", "planes_kernel"}
@@ -457,3 +490,31 @@ def test_graft_entry_build_runs_to_its_end():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_a_bare_load_of_the_library_ignores_the_nb_environment(tmp_path):
+    """the NB_* kernel-form overrides steer the library only after a diagnostic call has asked for them
+    (nb_diag_enable_env / nb_debug_reload_env: the test suite's fixtures, tools/).  In a fresh process with NB_FAST_PAIRS=0,
+    NB_TILE=256 and NB_STRICT_SL=0 exported, the plan of the headline shapes is the default one until then.  Host arithmetic only."""
+    import subprocess
+    import sys
+
+    code = """
+import ctypes, sys
+sys.path.insert(0, %r)
+from nenbody_amd import _lib
+lib = _lib.load()
+fast, strict = _lib.default_params(_lib.NB_MODE_FAST), _lib.default_params()
+def plan(p): return ",".join(_lib.planned_kernels(p, 131072, 131072))
+print(plan(fast), plan(strict), lib.nb_ring_partners(ctypes.byref(fast), 131072, 0, 16384))
+assert lib.nb_diag_enable_env(1) == 0
+print(plan(fast), plan(strict), lib.nb_ring_partners(ctypes.byref(fast), 131072, 0, 16384))
+assert lib.nb_diag_enable_env(0) == 0
+print(plan(fast), plan(strict), lib.nb_ring_partners(ctypes.byref(fast), 131072, 0, 16384))
+""" % ROOT
+    env = dict(os.environ, NB_FAST_PAIRS="0", NB_TILE="256", NB_STRICT_SL="0", NB_RING="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bare, enabled, again = r.stdout.strip().splitlines()
+    assert bare == again == "step_fast_pairs_kernel,planes_kernel,pairs_diag_kernel,pairs_integrate_kernel step_strict_sl_kernel,planes_kernel 4"
+    assert enabled.split()[0].startswith("step_fast_wave_kernel") and enabled.split()[1] == "step_strict_kernel" and enabled.split()[2] == "0"

@@ -7,6 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 import oracle  # noqa: E402  (baseline leg only)
 
 

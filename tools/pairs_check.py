@@ -1,6 +1,7 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nenbody_amd as nb
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 def run(n, env, steps=1, z=False):
     for k in ("NB_FAST_SL","NB_FAST_PAIRS","NB_FORCE_3D"): os.environ.pop(k, None)
     os.environ.update(env); nb.reload_env()

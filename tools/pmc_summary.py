@@ -55,12 +55,13 @@ def main(root, json_path=None, n=None, count=None, source=None):
             print(f"   -> wave time: issuing {vals['SQ_ACTIVE_INST_ANY'] / wc:.1%}, issue-stalled "
                   f"{vals.get('SQ_WAIT_INST_ANY', 0) / wc:.1%}, parked (s_waitcnt/barrier) {vals.get('SQ_WAIT_ANY', 0) / wc:.1%}")
     if json_path:
-        from nenbody_amd._lib import kernel_source_sha
+        from nenbody_amd._lib import kernel_code_sha, kernel_source_sha
 
         out = {"_comment": "HBM-side bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 1024 x 2 [gfx950 correction for wide "
                            "coalesced reads] + WRITE_SIZE x 1024). Written by tools/pmc_summary.py --json; bench.py reports the sum "
-                           "over a step's kernels as roofline.traffic when src_sha and the shape match.",
-               "n": n, "count": count, "src_sha": kernel_source_sha(), "source": source or root, "kernels": traffic}
+                           "over a step's kernels as roofline.traffic when code_sha (the device code of the benchmarked kernels in the "
+                           "built library, nenbody_amd/_lib.py:kernel_code_sha) and the shape match; src_sha is informational.",
+               "n": n, "count": count, "code_sha": kernel_code_sha(), "src_sha": kernel_source_sha(), "source": source or root, "kernels": traffic}
         json.dump(out, open(json_path, "w"), indent=1)
         print(f"wrote {json_path}: {sorted(traffic)}", file=sys.stderr)
 

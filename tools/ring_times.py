@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 from nenbody_amd.dist import HipBackend  # noqa: E402
 
 n_total = int(sys.argv[1]) if len(sys.argv) > 1 else 131072

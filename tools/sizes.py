@@ -7,6 +7,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 16384, 131072, 1 << 20]
 for n in sizes:

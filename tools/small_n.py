@@ -8,6 +8,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 
 sizes = [int(x) for x in sys.argv[1:]] or [100, 256, 1024, 2048, 4096, 16384]
 for n in sizes:

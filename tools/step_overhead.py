@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import nenbody_amd as nb  # noqa: E402
+nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
