@@ -252,6 +252,15 @@ int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t fi
 int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
                          const void *vel_in, void *pos_out, void *vel_out, void *stream);
 
+/* The same step with the j range cut into slices ("split" form, for shards whose bodies alone cannot fill the chip: a rank of an
+ * 8-GPU job): every radius test is evaluated on the reference's operands with the reference's bits, so the neighbour SETS and
+ * COUNTS are the reference's, but a body's sums are added slice by slice (in index order inside a slice, then in slice order --
+ * the same order every step) instead of in one index-ordered chain: results within a relative 1e-6 of the bit-exact step per
+ * step, not bit-identical.  Opt-in: nb_launch_boids_step stays the reference's arithmetic.  scratch: nb_boids_split_scratch_bytes(). */
+size_t nb_boids_split_scratch_bytes(const nb_boids_params *params, uint32_t n_total, uint32_t count);
+int nb_launch_boids_step_split(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
+                               const void *vel_in, void *pos_out, void *vel_out, void *scratch, size_t scratch_bytes, void *stream);
+
 /* Model matrices (main.rs:437-439) for `count` bodies: pos, vel -> inst (16 floats per body). */
 int nb_launch_instances(uint32_t count, const void *pos, const void *vel, void *inst_16n, void *stream);
 
@@ -309,6 +318,10 @@ typedef int (*nb_ring_fn)(void *user, const void *send, void *recv, size_t chunk
 int nb_shard_use_ring(nb_shard *sh, nb_ring_fn fn, void *user);
 int nb_shard_set_pairs(nb_shard *sh, int on);
 int nb_shard_pairs_partners(const nb_shard *sh);
+/* on != 0: nb_shard_step_boids takes the split form of the boids step (nb_launch_boids_step_split: the reference's neighbour sets
+ * and counts, sums reassociated) -- what lets eight ranks run the controller about seven times as fast as one instead of 3.4
+ * times; off (the default): bit-identical to the reference whatever the world size. */
+int nb_shard_set_boids_split(nb_shard *sh, int on);
 /* FAST only ("Overlap"): with `on` != 0 every step folds this rank's own slot of the snapshot while the
  * exchange of the other slots is still in flight on a second stream, waits for it, then folds the rest (the two phases of
  * nb_launch_step_phase).  The order of the additions changes, which FAST may and STRICT may not: a STRICT shard (and a world

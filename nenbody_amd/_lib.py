@@ -86,6 +86,9 @@ PROTOTYPES = {
     "nb_step_boids": (c_int, [c_void_p, c_uint32, POINTER(NbBoidsParams)]),
     "nb_launch_boids_step": (
         c_int, [POINTER(NbBoidsParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_boids_split_scratch_bytes": (c_size_t, [POINTER(NbBoidsParams), c_uint32, c_uint32]),
+    "nb_launch_boids_step_split": (
+        c_int, [POINTER(NbBoidsParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nb_step_random": (c_int, [c_void_p, c_uint32, c_uint64]),
     "nb_device_state": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "nb_cameras": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -129,6 +132,7 @@ PROTOTYPES = {
     "nb_shard_use_ring": (c_int, [c_void_p, RING_FN, c_void_p]),
     "nb_shard_set_pairs": (c_int, [c_void_p, c_int]),
     "nb_shard_pairs_partners": (c_int, [c_void_p]),
+    "nb_shard_set_boids_split": (c_int, [c_void_p, c_int]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
     "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nb_shard_step": (c_int, [c_void_p, c_uint32]),

@@ -48,7 +48,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -105,6 +105,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_pc = read_knob("NB_BOIDS_PC");
     d->boids_tile = read_knob("NB_BOIDS_TILE");
     d->boids_force = read_knob("NB_BOIDS_FORCE");
+    d->boids_slices = read_knob("NB_BOIDS_SLICES");
     d->dropin_zero_copy = read_knob("NB_DROPIN_ZERO_COPY");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
     return d;
@@ -744,6 +745,21 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
     *tile = t;
     return NB_OK;
 }
+
+// The split form of the boids step (nb_launch_boids_step_split): slices of the j range so that one lane per body per slice gives
+// the chip two waves per SIMD (512 workgroups of four waves), whole tiles per slice.  NB_BOIDS_SLICES names the count (tests, tools/).
+void boids_split_shape(uint32_t n_total, uint32_t count, uint32_t tile, uint32_t *slices, uint32_t *j_chunk)
+{
+    const uint32_t ntiles = (n_total + tile - 1u) / tile, groups = (count + 255u) / 256u;
+    uint32_t sl = overrides().boids_slices.or_else((512u + groups - 1u) / groups);
+    if (sl < 1u) sl = 1u;
+    if (sl > ntiles) sl = ntiles;
+    if (sl > 64u) sl = 64u;
+    const uint32_t per = (ntiles + sl - 1u) / sl;
+    *slices = (ntiles + per - 1u) / per;  // no empty slice
+    *j_chunk = per * tile;
+}
+size_t boids_split_bytes(uint32_t count, uint32_t slices) { return (size_t)slices * count * 3u * sizeof(float4); }
 
 // Launch-API calls run on the device that owns the caller's buffers, not on whatever device happens to be current in
 // this thread (one process per GPU normally makes them equal; a host that forgot hipSetDevice would otherwise launch on
@@ -2375,6 +2391,61 @@ NB_EXPORT int nb_launch_boids_step(const nb_boids_params *params, uint32_t n_tot
     hipError_t e = nbk::launch_boids(a, tile, boids_form(a.count), (hipStream_t)stream);
     if (e != hipSuccess) {
         g_tls_error = std::string("nb: boids kernel launch failed: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+
+NB_EXPORT size_t nb_boids_split_scratch_bytes(const nb_boids_params *params, uint32_t n_total, uint32_t count)
+{
+    nb_boids_params p;
+    if (params)
+        p = *params;
+    else
+        nb_boids_default_params(&p);
+    nbk::BoidsArgs a;
+    uint32_t tile = 0, slices = 0, chunk = 0;
+    std::string err;
+    if (make_boids_args(p, n_total, 0, count ? count : 1u, &a, &tile, &err) != NB_OK) return 0;
+    boids_split_shape(n_total, count, tile, &slices, &chunk);
+    return boids_split_bytes(count, slices);
+}
+
+NB_EXPORT int nb_launch_boids_step_split(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count,
+                                         const void *pos_in, const void *vel_in, void *pos_out, void *vel_out, void *scratch,
+                                         size_t scratch_bytes, void *stream)
+{
+    nb_boids_params p;
+    if (params)
+        p = *params;
+    else
+        nb_boids_default_params(&p);
+    if (!pos_in || !vel_in || !pos_out || !vel_out || !scratch || pos_in == pos_out || vel_in == vel_out) {
+        g_tls_error = "nb_launch_boids_step_split: buffers must be non-null and the outputs must not alias the inputs";
+        return NB_ERR_INVALID;
+    }
+    nbk::BoidsArgs a;
+    uint32_t tile = 0, slices = 0, chunk = 0;
+    int rc = make_boids_args(p, n_total, first, count, &a, &tile, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    boids_split_shape(n_total, count, tile, &slices, &chunk);
+    if (scratch_bytes < boids_split_bytes(count, slices)) {
+        g_tls_error = "nb_launch_boids_step_split: scratch smaller than nb_boids_split_scratch_bytes()";
+        return NB_ERR_INVALID;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    rc = select_device_of(pos_in, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    a.pos_in = (const float4 *)pos_in;
+    a.vel_in = (const float4 *)vel_in;
+    a.pos_out = (float4 *)pos_out;
+    a.vel_out = (float4 *)vel_out;
+    a.partial = (float4 *)scratch;
+    a.j_chunk = chunk;
+    hipError_t e = nbk::launch_boids_split(a, tile, slices, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb: boids kernel launch failed (split form): ") + hipGetErrorString(e);
         return NB_ERR_HIP;
     }
     return NB_OK;

@@ -53,12 +53,17 @@ struct BoidsArgs {
     float s1, s2, s3;      // rule scales, main.rs:454-456
     uint32_t force_flags;  // OR-ed into every tile's flags: 1 = never the masked-FMA form, 2 = never the planar form, 4 = always test rule 3 (tests)
     uint32_t vlim_bits;    // bit pattern of v_lim: velocity components of at most this magnitude cannot fail the rule-3 test (nb_boids.inc, ALL3)
+    float4 *partial;       // split form (launch_boids_split): [slices][count][3] records of partial sums
+    uint32_t j_chunk;      // split form: records per slice, a multiple of the tile
     uint32_t mk_valid;     // 1 = mk holds usable constants for all three radii (else: dummies, and force_flags bit 1 is set)
     BoidsMaskK mk;         // the three radius tests as single instructions (masked form only; the host clears the form where a radius has no such constants)
 };
 // form: 0 = one lane per body, 1 = producer/consumer (64 bodies x 16 waves), 2 = one lane per body with (x, y) packed,
 // 3 / 4 = chain split (two waves per 64 bodies: rule 1 | rules 2-3) plain / packed
 hipError_t launch_boids(const BoidsArgs &a, uint32_t tile, uint32_t form, hipStream_t s);
+// the split form (round 4): the j range in `slices` slices of a.j_chunk records, one lane per body per slice, the slices' sums added
+// in slice order by a second launch: the reference's predicates and counts, reassociated sums (a tolerance form for small shards)
+hipError_t launch_boids_split(const BoidsArgs &a, uint32_t tile, uint32_t slices, hipStream_t s);
 
 hipError_t launch_strict(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);
 hipError_t launch_strict_jp(const StepArgs &a, uint32_t tile, uint32_t unroll, uint32_t lanes, hipStream_t s);  // nb_kernels.hip, -DNBK_NOSLP_TU

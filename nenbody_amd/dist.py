@@ -112,6 +112,19 @@ class HipBackend:
                                             pos_out.data_ptr(), vel_out.data_ptr(), stream))
 
 
+    def boids_split_scratch_bytes(self, params, n_total, count) -> int:
+        return int(self.lib.nb_boids_split_scratch_bytes(ctypes.byref(params), n_total, count))
+
+    def boids_step_split(self, params, n_total, first, count, pos_in, vel_in, pos_out, vel_out, scratch) -> None:
+        """the boids step with the j range in slices (``nb_launch_boids_step_split``): the reference's neighbour sets and counts,
+        reassociated sums -- the form that lets a small shard fill the chip"""
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        check(self.lib.nb_launch_boids_step_split(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), vel_in.data_ptr(),
+                                                  pos_out.data_ptr(), vel_out.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+
+
 class ShardedScene:
     """One rank's share of a Scene: bodies [first, first+count) plus a replica of all positions.
 
@@ -230,10 +243,20 @@ class ShardedScene:
 
     # -- boids: update_instance_boids (main.rs:443-526) reads every old velocity, so velocities are replicated and
     #    gathered like positions ----------------------------------------------------------------------------------
-    def step_boids(self, params=None) -> None:
+    def step_boids(self, params=None, split: bool = False) -> None:
+        """One boids step.  split=True: the j range in slices (``nb_launch_boids_step_split``) -- the reference's neighbour sets
+        and counts with reassociated sums, for shards whose bodies alone cannot fill the chip; default: bit-identical."""
         torch = self.torch
         self._wait_pending()
         bp = params if params is not None else _lib.default_boids_params()
+        boids = self.backend.boids_step
+        if split and self.count and hasattr(self.backend, "boids_step_split"):
+            sb = self.backend.boids_split_scratch_bytes(bp, self.n, self.count)
+            if getattr(self, "_boids_partial", None) is None or self._boids_partial.numel() < sb:
+                self._boids_partial = torch.empty((sb,), dtype=torch.uint8, device=self.device)
+
+            def boids(p_, n_, f_, c_, a_, b_, c2_, d_):
+                self.backend.boids_step_split(p_, n_, f_, c_, a_, b_, c2_, d_, self._boids_partial)
         lo = self.rank * self.slot
         if self.velfull is None:
             padded = self.slot * self.world
@@ -255,14 +278,13 @@ class ShardedScene:
                 self._pvstage = torch.zeros((self.world * 2 * self.slot, 4), dtype=torch.float32, device=self.device)
             st = self._pvstage
             if self.count:
-                self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, st[self.rank * self.slot:],
-                                        st[self.rank * self.slot + self.slot:])
+                boids(bp, self.n, self.first, self.count, psrc, vsrc, st[self.rank * self.slot:], st[self.rank * self.slot + self.slot:])
             self._all_gather_slots(st, slot=2 * self.slot)
             both = st.view(self.world, 2, self.slot, 4)
             pdst.view(self.world, self.slot, 4).copy_(both[:, 0])
             vdst.view(self.world, self.slot, 4).copy_(both[:, 1])
         elif self.count:
-            self.backend.boids_step(bp, self.n, self.first, self.count, psrc, vsrc, pdst, vdst)
+            boids(bp, self.n, self.first, self.count, psrc, vsrc, pdst, vdst)
         if self.count:
             self.vel[: self.count] = vdst[lo:lo + self.count]  # keep the local velocities current for n-body steps
         self.cur ^= 1
@@ -362,7 +384,8 @@ class NativeShard:
     """
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, rank: int = 0, world: int = 1,
-                 comm_id: Optional[bytes] = None, gather=None, overlap: bool = False, ring=None, pairs: Optional[bool] = None):
+                 comm_id: Optional[bytes] = None, gather=None, overlap: bool = False, ring=None, pairs: Optional[bool] = None,
+                 boids_split: bool = False):
         lib = _lib.load()
         pos = np.ascontiguousarray(positions, dtype=np.float32)
         vel = np.ascontiguousarray(velocities, dtype=np.float32)
@@ -411,6 +434,8 @@ class NativeShard:
                 self._check(lib.nb_shard_use_ring(self._sh, self._ring_keepalive, None))
             if pairs is not None:
                 self._check(lib.nb_shard_set_pairs(self._sh, 1 if pairs else 0))
+            if boids_split:  # the boids step's j range in slices: the reference's neighbour sets and counts, reassociated sums
+                self._check(lib.nb_shard_set_boids_split(self._sh, 1))
             if overlap:  # FAST only; a STRICT shard ignores it (nb_shard_set_overlap)
                 self._check(lib.nb_shard_set_overlap(self._sh, 1))
             self._check(lib.nb_shard_upload(self._sh, pos.ctypes.data, vel.ctypes.data))

@@ -410,3 +410,143 @@ def test_boids_full_size_sampled_vs_oracle(nb, oracle):
         assert (bits(p[i]) == bits(p_ref[0])).all() and (bits(v[i]) == bits(v_ref[0])).all(), f"body {i}"
     speed = np.sqrt((v.astype(np.float64) ** 2).sum(axis=1))
     assert speed.max() <= 1.0 + 1e-6            # the clamp of main.rs:516-518
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the split form (round 4, nb_launch_boids_step_split): the j range in slices, one lane per body per slice, the slices' sums added
+# in slice order -- the reference's predicates on the reference's operands (same neighbour sets, same counts), reassociated sums
+# ---------------------------------------------------------------------------------------------------------------------------
+def split_step(nb, pos, vel, parts, bp=None):
+    """one boids step of the set, every (first, count) of `parts` through the split form on the one GPU"""
+    import torch
+
+    from nenbody_amd.dist import HipBackend
+
+    be, dev, n = HipBackend(), torch.device("cuda", 0), len(pos)
+    bp = bp if bp is not None else nb.default_boids_params()
+
+    def rec(a):
+        t = torch.zeros((n, 4), dtype=torch.float32)
+        t[:, :3] = torch.from_numpy(a)
+        return t.to(dev)
+
+    pin, vin = rec(pos), rec(vel)
+    pout, vout = torch.full_like(pin, float("nan")), torch.full_like(vin, float("nan"))
+    for first, count in parts:
+        scratch = torch.empty((max(16, be.boids_split_scratch_bytes(bp, n, count)),), dtype=torch.uint8, device=dev)
+        be.boids_step_split(bp, n, first, count, pin, vin, pout, vout, scratch)
+    torch.cuda.synchronize()
+    return pout[:, :3].cpu().numpy(), vout[:, :3].cpu().numpy()
+
+
+def close_to_the_reference(v, v_ref, p, p_ref, what=""):
+    """|dv| <= 1e-6 of the largest velocity component (the new velocity is a blend of three means of up to n terms; a reassociated
+    binary32 sum of n terms differs from the sequential one by ~sqrt(n) half-ulps), and positions follow (pos = vel * dt + pos)"""
+    sv = float(np.abs(v_ref).max())
+    assert np.abs(v - v_ref).max() <= 1e-6 * sv, f"{what}: max |dv| {np.abs(v - v_ref).max():.3e} against {1e-6 * sv:.3e}"
+    assert np.abs(p - p_ref).max() <= 1e-6 * sv + float(np.spacing(np.float32(np.abs(p_ref).max()))), what
+
+
+@pytest.mark.parametrize("slices", ["1", "2", "3", "7", "auto"])
+@pytest.mark.parametrize("n,parts", [(64, [(0, 64)]), (300, [(0, 300)]), (1025, [(0, 1), (1, 1024)]), (3000, [(0, 1000), (1000, 2000)]),
+                                     (20000, [(0, 2500), (2500, 17500)])], ids=lambda x: str(x) if isinstance(x, int) else "")
+def test_boids_split_form_vs_oracle(nb, oracle, monkeypatch, n, parts, slices):
+    if slices != "auto":
+        monkeypatch.setenv("NB_BOIDS_SLICES", slices)
+    for three_d in (True, False):
+        pos, vel = cloud(oracle, n, seed=n + 1) if three_d else (lambda pv: (pv[0] * np.float32(0.2), pv[1]))(oracle.init_state(n, n + 2))
+        p, v = split_step(nb, pos, vel, parts)
+        p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+        if slices == "1":            # one slice: the reference's order of additions, hence its bits
+            assert_bits_equal(v, v_ref, "one slice")
+            assert_bits_equal(p, p_ref, "one slice")
+        close_to_the_reference(v, v_ref, p, p_ref, f"n={n} slices={slices} 3d={three_d}")
+        p2, v2 = split_step(nb, pos, vel, parts)
+        assert_bits_equal(v, v2, "run to run")
+
+
+@pytest.mark.parametrize("knob", ["1", "2", "4", "6", "7"], ids=["select", "3d", "rule3-tested", "rule3-tested-3d", "select-3d-tested"])
+@pytest.mark.parametrize("tile", [256, 512, 1024])
+def test_boids_split_form_every_tile_form(nb, oracle, monkeypatch, knob, tile):
+    monkeypatch.setenv("NB_BOIDS_FORCE", knob)
+    monkeypatch.setenv("NB_BOIDS_SLICES", "5")
+    n = 6000
+    pos, vel = cloud(oracle, n, seed=77)
+    pos[300:500, 2] = 0
+    bp = nb.default_boids_params(tile=tile)
+    p, v = split_step(nb, pos, vel, [(0, 2000), (2000, 4000)], bp)
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    close_to_the_reference(v, v_ref, p, p_ref, f"force={knob} tile={tile}")
+
+
+def test_boids_split_form_radius_boundaries_and_custom_constants(nb, oracle, monkeypatch):
+    """the radius tests decide WHO is in a sum: at, just inside and just outside every radius the split form must make the
+    reference's choice (a wrong neighbour moves a mean by far more than a rounding), also with radii that cut"""
+    monkeypatch.setenv("NB_BOIDS_SLICES", "4")
+    xs, x = [np.float32(0)], np.float32(5.0)
+    for _ in range(6):
+        x = np.nextafter(x, np.float32(0))
+    for _ in range(13):
+        xs.append(x)
+        x = np.nextafter(x, np.float32(10))
+    x = np.float32(np.sqrt(1000.0))
+    for _ in range(4):
+        x = np.nextafter(x, np.float32(0))
+    for _ in range(9):
+        xs.append(x)
+        x = np.nextafter(x, np.float32(100))
+    reps = 60                                    # the boundary pairs spread over several 256-record tiles and slices
+    pos = np.zeros((len(xs) * reps, 3), np.float32)
+    pos[:, 0] = np.tile(xs, reps)
+    pos[:, 1] = np.repeat(np.arange(reps, dtype=np.float32) * np.float32(200.0), len(xs))   # replicas 200 apart: only their own pairs interact
+    pos[1::2, 1] += np.float32(1e-4)
+    vel = np.zeros_like(pos)
+    vel[:, 0] = np.linspace(0, 0.05, len(pos), dtype=np.float32)
+    bp = nb.default_boids_params(tile=256)
+    p, v = split_step(nb, pos, vel, [(0, len(pos))], bp)
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    close_to_the_reference(v, v_ref, p, p_ref, "boundaries")
+    pos, vel = cloud(oracle, 800, seed=5)
+    vel *= np.float32(30)
+    for r3, r2, r1 in [(1.0, 3.0, 400.0), (2.5, 0.0, 1e9), (np.inf, 7.5, 0.5), (0.5, -1.0, np.nan)]:
+        bp, obp = nb.default_boids_params(tile=256), oracle.boids_params()
+        for k, val in (("rule_3_distance", r3), ("rule_2_distance", r2), ("rule_1_distance", r1), ("dt", 0.1), ("rule_2_scale", 0.2)):
+            setattr(bp, k, val)
+            setattr(obp, k, val)
+        p, v = split_step(nb, pos, vel, [(0, 800)], bp)
+        p_ref, v_ref = oracle.boids_run(pos, vel, 1, obp)
+        close_to_the_reference(v, v_ref, p, p_ref, f"r3={r3} r2={r2} r1={r1}")
+
+
+def test_boids_split_form_nonfinite_records(nb, oracle, monkeypatch):
+    monkeypatch.setenv("NB_BOIDS_SLICES", "3")
+    n = 2600
+    pos, vel = oracle.init_state(n, seed=99)
+    pos *= np.float32(0.2)
+    pos[2000, 0] = np.inf
+    vel[100, 1] = np.nan
+    p, v = split_step(nb, pos, vel, [(0, n)])
+    p_ref, v_ref = oracle.boids_run(pos, vel, 1)
+    assert (np.isnan(p) == np.isnan(p_ref)).all() and (np.isnan(v) == np.isnan(v_ref)).all()
+    ok = ~np.isnan(v_ref).any(axis=1) & ~np.isnan(p_ref).any(axis=1)
+    close_to_the_reference(v[ok], v_ref[ok], p[ok], p_ref[ok], "finite bodies")
+
+
+def test_boids_split_form_at_the_headline_size(nb, oracle):
+    """every rank's (first, count) of an 8-rank job at N = 131 072 through the split form (the library's own slices), sampled bodies
+    of every rank against the oracle; then ShardedScene.step_boids(split=True) on a world of one"""
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    parts = nb.partition(n, 8)
+    p, v = split_step(nb, pos, vel, parts)
+    idx = np.unique(np.concatenate([[f, f + c - 1, f + c // 2, f + c // 3] for f, c in parts]))
+    sv = 0.0
+    refs = [oracle.boids_step_range(pos, vel, int(i), 1) for i in idx]
+    sv = max(float(np.abs(r[1]).max()) for r in refs)
+    for i, (p_ref, v_ref) in zip(idx, refs):
+        assert np.abs(v[i] - v_ref[0]).max() <= 1e-6 * sv and np.abs(p[i] - p_ref[0]).max() <= 1e-5, f"body {i}"
+    sc = nb.ShardedScene(pos[:4096], vel[:4096])
+    sc.step_boids(split=True)
+    sc.sync()
+    p_ref, v_ref = oracle.boids_run(pos[:4096], vel[:4096], 1)
+    close_to_the_reference(sc.velocities(), v_ref, sc.positions(), p_ref, "ShardedScene(split=True)")

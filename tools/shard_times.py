@@ -13,7 +13,7 @@ import nenbody_amd as nb  # noqa: E402
 nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 from nenbody_amd.dist import HipBackend  # noqa: E402
 
-what = sys.argv[1] if len(sys.argv) > 1 else "strict"
+what = sys.argv[1] if len(sys.argv) > 1 else "strict"   # strict | fast | boids | boids-split
 n_total = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 be = HipBackend()
 dev = torch.device("cuda", 0)
@@ -30,8 +30,12 @@ for count in (n_total, n_total // 2, n_total // 4, n_total // 8):
     sb = be.scratch_bytes(params, n_total, count)
     scratch = torch.empty((sb,), dtype=torch.uint8, device=dev) if sb else None
 
+    bscratch = torch.empty((max(16, be.boids_split_scratch_bytes(bp, n_total, count)),), dtype=torch.uint8, device=dev)
+
     def step():
-        if what == "boids":
+        if what == "boids-split":   # the j range in slices: the reference's neighbour sets and counts, reassociated sums
+            be.boids_step_split(bp, n_total, 0, count, cur, vin, nxt, vout, bscratch)
+        elif what == "boids":
             be.boids_step(bp, n_total, 0, count, cur, vin, nxt, vout)
         else:
             be.step(params, n_total, 0, count, cur, nxt, v4, scratch)
@@ -49,5 +53,5 @@ for count in (n_total, n_total // 2, n_total // 4, n_total // 8):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
     res[count] = best
-    kern = nb._lib.planned_kernels(params, n_total, count)[0] if what != "boids" else "boids"
+    kern = nb._lib.planned_kernels(params, n_total, count)[0] if not what.startswith("boids") else what
     print(f"{what} N={n_total} shard {count:7d}: {best:.3f} ms/step  x{res[n_total] / best:.2f} of the whole set  [{kern}]", flush=True)
