@@ -439,12 +439,52 @@ def split_step(nb, pos, vel, parts, bp=None):
     return pout[:, :3].cpu().numpy(), vout[:, :3].cpu().numpy()
 
 
-def close_to_the_reference(v, v_ref, p, p_ref, what=""):
-    """|dv| <= 1e-6 of the largest velocity component (the new velocity is a blend of three means of up to n terms; a reassociated
-    binary32 sum of n terms differs from the sequential one by ~sqrt(n) half-ulps), and positions follow (pos = vel * dt + pos)"""
+def boids_velocity_f64(pos, vel, i, bp):
+    """the new velocity of body i (main.rs:471-518) with the reference's binary32 PREDICATES -- the same neighbour sets -- and every
+    sum, mean and blend carried in binary64: the yardstick for the rounding error of a binary32 sum, the reference's included"""
+    f = np.float32
+    d = pos - pos[i]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    other = np.arange(len(pos)) != i
+    with np.errstate(invalid="ignore"):
+        p1 = (d2 < f(bp.rule_1_distance)) & other
+        p2 = (np.sqrt(d2) < f(bp.rule_2_distance)) & other
+        e = vel - vel[i]
+        e2 = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1]) + e[:, 2] * e[:, 2]
+        p3 = (np.sqrt(e2) < f(bp.rule_3_distance)) & other
+    c = pos[p1].astype(np.float64).sum(axis=0)
+    r = -(d[p2].astype(np.float64)).sum(axis=0)
+    m = vel[p3].astype(np.float64).sum(axis=0)
+    if p1.sum():
+        c = c / p1.sum()
+    if p3.sum():
+        m = m / p3.sum()
+    v = c * float(f(bp.rule_1_scale)) + r * float(f(bp.rule_2_scale)) + m * float(f(bp.rule_3_scale))
+    mag = np.sqrt((v * v).sum())
+    return v / mag if mag > 1.0 else v
+
+
+def close_to_the_reference(v, v_ref, p, p_ref, what="", state=None):
+    """The split form against the bit-exact step.  Its neighbour sets and counts are the reference's; its sums are binary32 sums in
+    another order, and a sequential binary32 sum of m terms carries ~sqrt(m) half-ulps of its own (6.9e-6 of a unit velocity on
+    20 000 bodies in a 40 x 40 square), so "close" means: every body within 5e-5 of the largest velocity component, and -- with
+    `state` = (pos, vel, bp) -- on the 48 bodies where the two differ most, plus 16 evenly spaced ones, the split form is NO FURTHER
+    from the same sums carried in binary64 than the reference's own arithmetic is: worst body against worst body (plus four
+    ulps of the result) and on average (body by body the two errors are independent: either may be the larger)."""
     sv = float(np.abs(v_ref).max())
-    assert np.abs(v - v_ref).max() <= 1e-6 * sv, f"{what}: max |dv| {np.abs(v - v_ref).max():.3e} against {1e-6 * sv:.3e}"
-    assert np.abs(p - p_ref).max() <= 1e-6 * sv + float(np.spacing(np.float32(np.abs(p_ref).max()))), what
+    dv = np.abs(v - v_ref).max(axis=1)
+    assert dv.max() <= 5e-5 * sv, f"{what}: max |dv| {dv.max():.3e} against {5e-5 * sv:.3e}"
+    assert np.abs(p - p_ref).max() <= 5e-5 * sv + float(np.spacing(np.float32(np.abs(p_ref).max()))), what
+    if state is None:
+        return
+    pos, vel, bp = state
+    chosen = np.unique(np.concatenate([np.argsort(dv)[-48:], np.linspace(0, len(v) - 1, 16).astype(np.int64)]))
+    ulp = float(np.spacing(np.float32(sv)))
+    v64 = np.array([boids_velocity_f64(pos, vel, int(i), bp) for i in chosen])
+    err_split, err_ref = np.abs(v[chosen] - v64).max(axis=1), np.abs(v_ref[chosen] - v64).max(axis=1)
+    # the worst body against the reference's worst, and body by body with the slack of two independent roundings of a mean
+    assert err_split.max() <= err_ref.max() + 4 * ulp, f"{what}: split {err_split.max():.3e} from the binary64 sums, the reference {err_ref.max():.3e}"
+    assert err_split.mean() <= 1.5 * err_ref.mean() + ulp, f"{what}: mean error split {err_split.mean():.3e}, the reference {err_ref.mean():.3e}"
 
 
 @pytest.mark.parametrize("slices", ["1", "2", "3", "7", "auto"])
@@ -460,7 +500,7 @@ def test_boids_split_form_vs_oracle(nb, oracle, monkeypatch, n, parts, slices):
         if slices == "1":            # one slice: the reference's order of additions, hence its bits
             assert_bits_equal(v, v_ref, "one slice")
             assert_bits_equal(p, p_ref, "one slice")
-        close_to_the_reference(v, v_ref, p, p_ref, f"n={n} slices={slices} 3d={three_d}")
+        close_to_the_reference(v, v_ref, p, p_ref, f"n={n} slices={slices} 3d={three_d}", (pos, vel, nb.default_boids_params()))
         p2, v2 = split_step(nb, pos, vel, parts)
         assert_bits_equal(v, v2, "run to run")
 
@@ -476,7 +516,7 @@ def test_boids_split_form_every_tile_form(nb, oracle, monkeypatch, knob, tile):
     bp = nb.default_boids_params(tile=tile)
     p, v = split_step(nb, pos, vel, [(0, 2000), (2000, 4000)], bp)
     p_ref, v_ref = oracle.boids_run(pos, vel, 1)
-    close_to_the_reference(v, v_ref, p, p_ref, f"force={knob} tile={tile}")
+    close_to_the_reference(v, v_ref, p, p_ref, f"force={knob} tile={tile}", (pos, vel, bp))
 
 
 def test_boids_split_form_radius_boundaries_and_custom_constants(nb, oracle, monkeypatch):
@@ -505,7 +545,7 @@ def test_boids_split_form_radius_boundaries_and_custom_constants(nb, oracle, mon
     bp = nb.default_boids_params(tile=256)
     p, v = split_step(nb, pos, vel, [(0, len(pos))], bp)
     p_ref, v_ref = oracle.boids_run(pos, vel, 1)
-    close_to_the_reference(v, v_ref, p, p_ref, "boundaries")
+    close_to_the_reference(v, v_ref, p, p_ref, "boundaries", (pos, vel, bp))
     pos, vel = cloud(oracle, 800, seed=5)
     vel *= np.float32(30)
     for r3, r2, r1 in [(1.0, 3.0, 400.0), (2.5, 0.0, 1e9), (np.inf, 7.5, 0.5), (0.5, -1.0, np.nan)]:
@@ -515,7 +555,7 @@ def test_boids_split_form_radius_boundaries_and_custom_constants(nb, oracle, mon
             setattr(obp, k, val)
         p, v = split_step(nb, pos, vel, [(0, 800)], bp)
         p_ref, v_ref = oracle.boids_run(pos, vel, 1, obp)
-        close_to_the_reference(v, v_ref, p, p_ref, f"r3={r3} r2={r2} r1={r1}")
+        close_to_the_reference(v, v_ref, p, p_ref, f"r3={r3} r2={r2} r1={r1}", (pos, vel, bp))
 
 
 def test_boids_split_form_nonfinite_records(nb, oracle, monkeypatch):
@@ -543,8 +583,12 @@ def test_boids_split_form_at_the_headline_size(nb, oracle):
     sv = 0.0
     refs = [oracle.boids_step_range(pos, vel, int(i), 1) for i in idx]
     sv = max(float(np.abs(r[1]).max()) for r in refs)
+    bp = nb.default_boids_params()
+    ulp = float(np.spacing(np.float32(sv)))
     for i, (p_ref, v_ref) in zip(idx, refs):
-        assert np.abs(v[i] - v_ref[0]).max() <= 1e-6 * sv and np.abs(p[i] - p_ref[0]).max() <= 1e-5, f"body {i}"
+        assert np.abs(v[i] - v_ref[0]).max() <= 5e-5 * sv and np.abs(p[i] - p_ref[0]).max() <= 1e-5, f"body {i}"
+        v64 = boids_velocity_f64(pos, vel, int(i), bp)
+        assert np.abs(v[i] - v64).max() <= np.abs(v_ref[0] - v64).max() + 2e-6 * sv + 0 * ulp, f"body {i}: further from the binary64 sums than the reference"
     sc = nb.ShardedScene(pos[:4096], vel[:4096])
     sc.step_boids(split=True)
     sc.sync()
