@@ -9,7 +9,7 @@
 #                               profiles/hbm_traffic.json)
 # The program after `--` is python3 itself (no env / bash -c hop: the profiler has initialised the GPU by then).
 set -u
-OUT=${1:-gpurun_out/prof_r03}
+OUT=${1:-gpurun_out/prof_r04}
 ROOT=$(pwd)
 mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
@@ -31,5 +31,15 @@ for mode in strict fast; do
         rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc/${mode}_p$i" -- python3 "$ROOT/bench.py" --mode $mode --no-secondary --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc/${mode}_p$i.log" 2>&1
         echo "pmc $mode pass $i ($set) rc=$?"
     done
+done
+# the pairs form on shards (tools/ring_times.py: rank 0 and rank 7 of eight at N = 131 072): kernel trace + the two HBM counters
+mkdir -p "$OUT/stats_ring"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_ring" -- python3 "$ROOT/tools/ring_times.py" 131072 8 > "$OUT/ring_under_rocprof.log" 2>&1
+echo "stats ring rc=$?"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "VALUBusy VALUUtilization"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_ring/ring_p$i" -- python3 "$ROOT/tools/ring_times.py" 131072 8 > "$OUT/pmc_ring_p$i.log" 2>&1
+    echo "pmc ring pass $i ($set) rc=$?"
 done
 find "$OUT" -name "*.csv" | wc -l
