@@ -434,6 +434,22 @@ def main():
                                                               "note": "planar tiles whose velocities cannot fail the rule-3 test "
                                                                       "(the reference's constants: every tile); 21 when it is tested; each "
                                                                       "radius test is one fma with a clamp"}}
+            if world > 1:
+                # the opt-in split form (the reference's neighbour sets and counts, reassociated sums): what lets a small shard fill the chip
+                for _ in range(3):
+                    sc.step_boids(split=True)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(bsteps):
+                    sc.step_boids(split=True)
+                torch.cuda.synchronize()
+                dist.barrier()
+                bt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=sc.device)
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+                line["boids_controller"]["split_form"] = {"what": "nb_launch_boids_step_split: the j range in slices, the reference's predicates and "
+                                                                  "counts, sums added slice by slice (not bit-identical)",
+                                                          "value": n * bsteps / float(bt.item()), "ms_per_step": 1e3 * float(bt.item()) / bsteps}
         except Exception as e:  # pragma: no cover
             line["boids_controller"] = {"error": repr(e)}
 

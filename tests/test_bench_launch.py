@@ -52,6 +52,7 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     assert pairs["partners"] == 1 and pairs["roofline"]["kernel"] == "step_fast_ring_kernel" and pairs["value"] > 0
     assert 0 < pairs["roofline"]["frac"] < 1 and pairs["roofline"]["frac_nominal"] > pairs["roofline"]["frac"]
     assert set(line["unpreheated"]) >= {"strict", "fast"}
+    assert line["boids_controller"]["split_form"]["value"] > 0
 
 
 def _preheat_rank(rank, world, port, out_dir):

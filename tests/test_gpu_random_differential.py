@@ -153,3 +153,45 @@ def test_fast_pairs_form_random_problems(nb, oracle, monkeypatch, case):
     acc = np.abs(ref_v - vel).max()
     assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, f"case {case}: n={n} w={w} np={np_}"
     assert np.abs(got_p - ref_p).max() <= 1e-5, f"case {case}"
+
+
+@pytest.mark.parametrize("case", range(max(12, CASES // 2)))
+def test_fast_pairs_form_on_shards_random_problems(nb, oracle, monkeypatch, case):
+    """the FAST pairs form across the ranks of a multi-GPU job (nb_launch_ring_fold / _finish; every rank's launches on the one GPU,
+    the second exchange by hand) over random rank counts, blocks per rank, bodies per lane, a-blocks per launch and waves per a-block,
+    planar / 3-D / partly planar data, other constants: within FAST's tolerance of the oracle, identical bits from run to run, and
+    -- the same pairs, evaluated once on one side instead of twice -- close to the one-GPU FAST step"""
+    from test_gpu_ring import ring_steps_on_one_gpu
+
+    rng = np.random.default_rng(9000 + case)
+    np_ = int(rng.choice([2, 4]))
+    world = int(rng.choice([2, 3, 4, 5, 8]))
+    nb_per_rank = int(rng.integers(1, 7 if np_ == 4 else 10))
+    n = 128 * np_ * nb_per_rank * world
+    monkeypatch.setenv("NB_RING", "1")
+    monkeypatch.setenv("NB_RING_NP", str(np_))
+    if case % 3 == 1:
+        monkeypatch.setenv("NB_RING_GA", str(int(rng.integers(1, nb_per_rank + 1))))
+    if case % 4 >= 2:
+        monkeypatch.setenv("NB_RING_WPB", str(4 * int(rng.integers(1, 9))))
+    if case % 5 == 4:
+        monkeypatch.setenv("NB_FAST_NO_SHARE", "1")
+    p = nb.default_params(mode=nb.NB_MODE_FAST)
+    p.dt = float(rng.choice([0.1, 0.01]))
+    p.G = float(rng.choice([0.001, 1.0, -0.05]))
+    p.bias = float(rng.choice([1e-7, 1e-3, 2.0]))
+    pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
+    vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
+    if case % 2 == 0:
+        pos[:, 2] = 0
+        vel[:, 2] = 0
+    elif case % 4 == 1:
+        pos[: n // 2, 2] = 0         # planar a sides meet 3-D b sides: one flag for the step
+    what = f"case {case}: n={n} world={world} np={np_} blocks/rank={nb_per_rank} G={p.G} bias={p.bias}"
+    got_p, got_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1)
+    again_p, again_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1)
+    assert (bits(got_p) == bits(again_p)).all() and (bits(got_v) == bits(again_v)).all(), what + ": not deterministic"
+    ref_p, ref_v = oracle.run(pos, vel, 1, np.float32(p.dt), np.float32(p.G), np.float32(p.bias))
+    acc = np.abs(ref_v - vel).max()
+    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, what
+    assert np.abs(got_p - ref_p).max() <= 2e-5 * acc + 1.6e-5, what
