@@ -42,4 +42,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
     rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_ring/ring_p$i" -- python3 "$ROOT/tools/ring_times.py" 131072 8 > "$OUT/pmc_ring_p$i.log" 2>&1
     echo "pmc ring pass $i ($set) rc=$?"
 done
+# the smoke of the same sources on the same box, beside the profiles (collect_profiles.sh copies it: no stale smoke.log)
+python3 -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+echo "smoke rc=$?"
 find "$OUT" -name "*.csv" | wc -l
