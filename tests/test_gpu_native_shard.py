@@ -270,13 +270,15 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
     schedule = (("nbody", 2), ("nbody", 1))
     import torch.multiprocessing as mp
 
-    for with_ring in (True, False):
-        out = tmp_path / ("ring" if with_ring else "ordered")
+    # (the last arm: the pairs form with nb_shard_set_overlap requested as well -- the ring comes first, and the scratch the
+    # overlapped phases would need must not replace the larger one the ring needs)
+    for with_ring, overlap in ((True, False), (False, False), (True, True)):
+        out = tmp_path / (("ring" if with_ring else "ordered") + ("-overlap" if overlap else ""))
         out.mkdir()
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(out), False, schedule, with_ring, 77), nprocs=world, join=True)
+        mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(out), overlap, schedule, with_ring, 77), nprocs=world, join=True)
         pos, vel = oracle.init_state(n, 77)
         p_ref, v_ref = reference(oracle, pos, vel, schedule)
         for r in range(world):
