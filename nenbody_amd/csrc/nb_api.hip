@@ -759,7 +759,19 @@ void boids_split_shape(uint32_t n_total, uint32_t count, uint32_t tile, uint32_t
     *slices = (ntiles + per - 1u) / per;  // no empty slice
     *j_chunk = per * tile;
 }
-size_t boids_split_bytes(uint32_t count, uint32_t slices) { return (size_t)slices * count * 3u * sizeof(float4); }
+// the slices' rows, then the per-1024-record velocity sums of the whole set, then the step's flag word
+size_t boids_split_rows_bytes(uint32_t count, uint32_t slices) { return (size_t)slices * count * 3u * sizeof(float4); }
+size_t boids_split_bytes(uint32_t n_total, uint32_t count, uint32_t slices)
+{
+    return boids_split_rows_bytes(count, slices) + (size_t)((n_total + 1023u) / 1024u) * sizeof(float4) + 64u;
+}
+void boids_split_pointers(nbk::BoidsArgs *a, void *scratch, uint32_t slices, uint32_t chunk)
+{
+    a->partial = (float4 *)scratch;
+    a->j_chunk = chunk;
+    a->vtot = (float4 *)((char *)scratch + boids_split_rows_bytes(a->count, slices));
+    a->gflags = (uint32_t *)(a->vtot + (a->n_total + 1023u) / 1024u);
+}
 
 // Launch-API calls run on the device that owns the caller's buffers, not on whatever device happens to be current in
 // this thread (one process per GPU normally makes them equal; a host that forgot hipSetDevice would otherwise launch on
@@ -2408,7 +2420,7 @@ NB_EXPORT size_t nb_boids_split_scratch_bytes(const nb_boids_params *params, uin
     std::string err;
     if (make_boids_args(p, n_total, 0, count ? count : 1u, &a, &tile, &err) != NB_OK) return 0;
     boids_split_shape(n_total, count, tile, &slices, &chunk);
-    return boids_split_bytes(count, slices);
+    return boids_split_bytes(n_total, count, slices);
 }
 
 NB_EXPORT int nb_launch_boids_step_split(const nb_boids_params *params, uint32_t n_total, uint32_t first, uint32_t count,
@@ -2429,7 +2441,7 @@ NB_EXPORT int nb_launch_boids_step_split(const nb_boids_params *params, uint32_t
     int rc = make_boids_args(p, n_total, first, count, &a, &tile, &g_tls_error);
     if (rc != NB_OK) return rc;
     boids_split_shape(n_total, count, tile, &slices, &chunk);
-    if (scratch_bytes < boids_split_bytes(count, slices)) {
+    if (scratch_bytes < boids_split_bytes(n_total, count, slices)) {
         g_tls_error = "nb_launch_boids_step_split: scratch smaller than nb_boids_split_scratch_bytes()";
         return NB_ERR_INVALID;
     }
@@ -2441,8 +2453,7 @@ NB_EXPORT int nb_launch_boids_step_split(const nb_boids_params *params, uint32_t
     a.vel_in = (const float4 *)vel_in;
     a.pos_out = (float4 *)pos_out;
     a.vel_out = (float4 *)vel_out;
-    a.partial = (float4 *)scratch;
-    a.j_chunk = chunk;
+    boids_split_pointers(&a, scratch, slices, chunk);
     hipError_t e = nbk::launch_boids_split(a, tile, slices, (hipStream_t)stream);
     if (e != hipSuccess) {
         g_tls_error = std::string("nb: boids kernel launch failed (split form): ") + hipGetErrorString(e);

@@ -55,6 +55,8 @@ struct BoidsArgs {
     uint32_t vlim_bits;    // bit pattern of v_lim: velocity components of at most this magnitude cannot fail the rule-3 test (nb_boids.inc, ALL3)
     float4 *partial;       // split form (launch_boids_split): [slices][count][3] records of partial sums
     uint32_t j_chunk;      // split form: records per slice, a multiple of the tile
+    float4 *vtot;          // split form: per-1024-record sums of all velocities (boids_prep_kernel), ceil(n_total / 1024) records
+    uint32_t *gflags;      // split form: the step's global flags (non-finite record / velocity above the rule-3 bound); NULL: rule 3 stays in the loops
     uint32_t mk_valid;     // 1 = mk holds usable constants for all three radii (else: dummies, and force_flags bit 1 is set)
     BoidsMaskK mk;         // the three radius tests as single instructions (masked form only; the host clears the form where a radius has no such constants)
 };
