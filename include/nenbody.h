@@ -320,7 +320,7 @@ int nb_shard_use_ring(nb_shard *sh, nb_ring_fn fn, void *user);
 int nb_shard_set_pairs(nb_shard *sh, int on);
 int nb_shard_pairs_partners(const nb_shard *sh);
 /* on != 0: nb_shard_step_boids takes the split form of the boids step (nb_launch_boids_step_split: the reference's neighbour sets
- * and counts, sums reassociated) -- what lets eight ranks run the controller about seven times as fast as one instead of 3.4
+ * and counts, sums reassociated) -- what lets eight ranks run the controller about eight times as fast as one instead of 3.4
  * times; off (the default): bit-identical to the reference whatever the world size. */
 int nb_shard_set_boids_split(nb_shard *sh, int on);
 /* FAST only ("Overlap"): with `on` != 0 every step folds this rank's own slot of the snapshot while the

@@ -294,3 +294,24 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
             assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r} velocities: {np.quantile(dv, 0.999) / scale:.2e} {dv.max() / scale:.2e}"
             dp = np.abs(got["pos"] - p_ref).max(axis=1)
             assert np.quantile(dp, 0.999) <= 2e-4 * scale and dp.max() <= 2e-2 * scale, f"rank {r} positions (replica)"
+
+
+def test_native_shard_boids_split_form(nb, oracle):
+    """nb_shard_set_boids_split: the boids step of the native shard with its j range in slices (the reference's neighbour sets and
+    counts, reassociated sums; rule 3 from the total of the velocities where it holds for every pair) -- close to the bit-exact
+    step, identical from run to run, and mixing with n-body steps keeps working (the velocity replica is rebuilt)"""
+    n = 6000
+    pos, vel = oracle.init_state(n, 5)
+    pos *= np.float32(0.3)
+    outs = []
+    for _ in range(2):
+        with nb.NativeShard(pos, vel, boids_split=True) as sh:
+            sh.step_boids(2)
+            sh.step(1)
+            sh.step_boids(1)
+            sh.sync()
+            outs.append((sh.positions(), sh.local_velocities()))
+    assert_bits_equal(outs[0][0], outs[1][0], "run to run")
+    assert_bits_equal(outs[0][1], outs[1][1], "run to run")
+    p_ref, v_ref = reference(oracle, pos, vel, (("boids", 2), ("nbody", 1), ("boids", 1)))
+    assert np.abs(outs[0][1] - v_ref).max() <= 1e-4 * np.abs(v_ref).max() and np.abs(outs[0][0] - p_ref).max() <= 1e-4
