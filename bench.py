@@ -65,7 +65,11 @@ def committed_traffic(nb, kernels, n, count):
         t = json.load(open(path))
     except Exception as e:
         return None, f"no usable profiles/hbm_traffic.json ({e.__class__.__name__})"
-    if t.get("code_sha") != nb._lib.kernel_code_sha():
+    try:
+        running = nb._lib.kernel_code_sha()
+    except Exception as e:   # (a library built another way -- compressed offload bundles, say: no stamp to compare, no traffic reported)
+        return None, f"the built library's device code could not be hashed ({e.__class__.__name__}: {e}): traffic not reported"
+    if t.get("code_sha") != running:
         return None, "profiles/hbm_traffic.json was measured on other device code (code_sha differs from the built library's): stale, not reported"
     if t.get("n") != n or t.get("count") != count:
         return None, "profiles/hbm_traffic.json is for another shape"
