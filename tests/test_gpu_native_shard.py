@@ -315,3 +315,30 @@ def test_native_shard_boids_split_form(nb, oracle):
     assert_bits_equal(outs[0][1], outs[1][1], "run to run")
     p_ref, v_ref = reference(oracle, pos, vel, (("boids", 2), ("nbody", 1), ("boids", 1)))
     assert np.abs(outs[0][1] - v_ref).max() <= 1e-4 * np.abs(v_ref).max() and np.abs(outs[0][0] - p_ref).max() <= 1e-4
+
+
+def test_rccl_leg_of_the_pairs_form_on_a_one_rank_communicator(nb, oracle):
+    """The RCCL calls of a pairs-form step -- ncclGroupStart, D x (ncclSend, ncclRecv), ncclGroupEnd, then ncclAllGather -- on the
+    library's stream, with rank 0 of EIGHT on a communicator of ONE (nb_diag_rccl_solo: the sends go to the rank itself, the
+    gather moves nothing): the whole call path of the second exchange on a one-GPU box.  The physics of such a step means nothing
+    (the rank receives its own halves back); what is held is that every call succeeds, the step completes and stays finite, and
+    the shard reports the form it took."""
+    n = 131072
+    pos, vel = nb.init_state(n, 1234)
+    lib = nb.load()
+    lib.nb_diag_rccl_solo(1)
+    try:
+        with nb.NativeShard(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST), rank=0, world=8, comm_id=nb.comm_id()) as sh:
+            assert sh.partners == 4 and (sh.first, sh.count) == (0, 16384)
+            sh.step(3)
+            sh.sync()
+            p, v = sh.positions(), sh.local_velocities()
+        with nb.NativeShard(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST), rank=0, world=8, comm_id=nb.comm_id(), pairs=False) as sh:
+            assert sh.partners == 0
+            sh.step(1)
+            sh.sync()
+    finally:
+        lib.nb_diag_rccl_solo(0)
+    assert np.isfinite(p).all() and np.isfinite(v).all()
+    assert (p[16384:] == pos[16384:]).all()          # the other ranks' slots: nothing arrived, nothing was touched
+    assert np.abs(p[:16384] - pos[:16384]).max() > 0
