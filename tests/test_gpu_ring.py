@@ -227,3 +227,17 @@ def test_ring_form_tracks_the_reference_as_the_one_gpu_fast_step_does(nb, capsys
               f"{np.quantile(d8, 0.999):.1e} / {np.median(d8):.1e}; one GPU {d1.max():.1e} / {np.quantile(d1, 0.999):.1e} / {np.median(d1):.1e}")
     assert np.median(d8) < 1e-4 and np.quantile(d8, 0.999) < 2e-3
     assert np.median(d8) <= 2 * np.median(d1) + 1e-5 and np.quantile(d8, 0.999) <= 3 * np.quantile(d1, 0.999) + 1e-5
+
+
+def test_ring_form_is_deterministic_and_finite_through_the_collapse(nb):
+    """100 steps of the headline set on 8 ranks in the pairs form, twice: the same bits (no sum depends on which workgroup or
+    which rank finished first: rows in a-block order, quarters in order, received chunks in ascending distance), and no body goes
+    non-finite while the cloud collapses and rebounds (step ~40)"""
+    n, world = 131072, 8
+    pos, vel = nb.init_state(n, 1234)
+    fast = nb.default_params(mode=nb.NB_MODE_FAST)
+    pa, va = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100)
+    pb, vb = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100)
+    assert (bits(pa) == bits(pb)).all() and (bits(va) == bits(vb)).all()
+    assert np.isfinite(pa).all() and np.isfinite(va).all()
+    assert (pa[:, 2] == 0).all()
