@@ -30,6 +30,14 @@ int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, u
 int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair);
 int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
 
+/* Diagnostic for integrators: do the model matrices (src/main.rs:437-439) of THIS device equal what THIS host's C library computes
+ * -- the reference's f32::atan2 / sin_cos bind to it?  The library restates glibc 2.35's atan2f / sinf / cosf for the device
+ * (nenbody_amd/csrc/nb_libm.h); on a host with another libm a few arguments in a billion round differently.  `count` (<= 2^26)
+ * seeded velocities -- the step's own range, every binade 2^-40 .. 2^40, any direction, near the axes and diagonals -- through
+ * nb_launch_instances and through the host's atan2f / sinf / cosf: *mismatches = matrices whose rotation entries differ in some
+ * bit (0 on the hosts the library was built for); bad_velocity (may be NULL) receives one offending (x, y). */
+int nb_selftest_matrices(uint32_t count, uint64_t seed, uint64_t *mismatches, float *bad_velocity);
+
 /* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
  * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.
  * mix 0: v_fma_f32 only (x 2 flop = the rate the 157.3 TFLOP/s spec peak assumes at 2.4 GHz); mix 1: fma / add / mul / sub in

@@ -1660,6 +1660,76 @@ NB_EXPORT int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uin
     return NB_OK;
 }
 
+// Do the model matrices of THIS device equal what THIS host's C library computes?  nb_libm.h restates one libm (glibc 2.35, the
+// build of sinf / cosf it selects on CPUs with FMA); a host with another one -- musl, a glibc with CORE-MATH's correctly rounded
+// sinf -- rounds a few arguments in a billion differently.  `count` velocities (the step's own range, every binade 2^-40..2^40,
+// near-axis directions) go through nb_launch_instances and through the host's atan2f / sinf / cosf; *mismatches = matrices whose
+// rotation entries differ in some bit (0 on the hosts this was built for); bad_velocity, if non-NULL, receives one offender (x, y).
+NB_EXPORT int nb_selftest_matrices(uint32_t count, uint64_t seed, uint64_t *mismatches, float *bad_velocity)
+{
+    if (!mismatches || count == 0 || count > (1u << 26)) {
+        g_tls_error = "nb_selftest_matrices: need mismatches != NULL and 0 < count <= 2^26";
+        return NB_ERR_INVALID;
+    }
+    int rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    std::vector<float4> pos(count), vel(count);
+    uint64_t st = seed;
+    for (uint32_t i = 0; i < count; ++i) {
+        float x, y;
+        switch (i & 3u) {
+        case 0: x = uniform_f32(st, -0.2f, 0.2f), y = uniform_f32(st, -0.2f, 0.2f); break;   // what a step produces
+        case 1: {                                                                              // every binade, either sign
+            const int ex = (int)(splitmix64(st) % 81u) - 40, ey = (int)(splitmix64(st) % 81u) - 40;
+            x = std::ldexp(uniform_f32(st, 1.0f, 2.0f), ex) * ((splitmix64(st) & 1u) ? -1.f : 1.f);
+            y = std::ldexp(uniform_f32(st, 1.0f, 2.0f), ey) * ((splitmix64(st) & 1u) ? -1.f : 1.f);
+            break;
+        }
+        case 2: {                                                                              // any direction, any length
+            const float ang = uniform_f32(st, -3.14159f, 3.14159f), r = std::ldexp(1.0f, (int)(splitmix64(st) % 41u) - 20);
+            x = r * std::cos(ang), y = r * std::sin(ang);
+            break;
+        }
+        default: {                                                                             // near the axes and the diagonals
+            static const float bx[8] = {1, 0, -1, 0, 1, -1, 1, -1}, by[8] = {0, 1, 0, -1, 1, 1, -1, -1};
+            const uint32_t k = (uint32_t)(splitmix64(st) & 7u);
+            const float eps = std::ldexp(1.0f, -(int)(splitmix64(st) % 30u) - 1);
+            x = bx[k] + uniform_f32(st, -1.f, 1.f) * eps, y = by[k] + uniform_f32(st, -1.f, 1.f) * eps;
+        }
+        }
+        vel[i] = make_float4(x, y, 0.f, 0.f);
+        pos[i] = make_float4(uniform_f32(st, -100.f, 100.f), uniform_f32(st, -100.f, 100.f), 0.f, 0.f);
+    }
+    float4 *d_pos = nullptr, *d_vel = nullptr, *d_inst = nullptr;
+    std::vector<float4> inst((size_t)count * 4);
+    hipError_t e = hipMalloc((void **)&d_pos, (size_t)count * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_vel, (size_t)count * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_inst, (size_t)count * 4 * sizeof(float4));
+    if (e == hipSuccess) e = hipMemcpy(d_pos, pos.data(), (size_t)count * sizeof(float4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_vel, vel.data(), (size_t)count * sizeof(float4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = nbk::launch_instances(count, d_pos, d_vel, d_inst, nullptr, 0u);
+    if (e == hipSuccess) e = hipMemcpy(inst.data(), d_inst, (size_t)count * 4 * sizeof(float4), hipMemcpyDeviceToHost);
+    for (void *p : {(void *)d_pos, (void *)d_vel, (void *)d_inst})
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_selftest_matrices: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    uint64_t bad = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const float theta = std::atan2(vel[i].y, vel[i].x);   // the float overloads: the host's atan2f / sinf / cosf
+        const float sn = std::sin(theta), cs = std::cos(theta);
+        const float4 c0 = inst[(size_t)i * 4], c1 = inst[(size_t)i * 4 + 1];
+        const float want[4] = {cs, sn, -sn, cs}, got[4] = {c0.x, c0.y, c1.x, c1.y};
+        if (std::memcmp(want, got, sizeof(want)) != 0) {
+            if (bad == 0 && bad_velocity) bad_velocity[0] = vel[i].x, bad_velocity[1] = vel[i].y;
+            ++bad;
+        }
+    }
+    *mismatches = bad;
+    return NB_OK;
+}
+
 NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
 {
     if (!violations || k_lo > k_hi || k_lo < -125 || k_hi > 125) {

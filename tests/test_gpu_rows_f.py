@@ -218,3 +218,12 @@ def test_model_matrices_are_bit_identical(nb, oracle, monkeypatch):
     differing = int((bits(old[finite]) != bits(ref[finite])).any(axis=(1, 2)).sum())
     print(f"device libm: {differing} of {int(finite.sum())} matrices differ from the host's in some word")
     assert differing > 0
+
+
+def test_library_selftest_of_the_matrices_against_the_host_libm(nb):
+    """nb_selftest_matrices (include/nenbody_diag.h): the check an integrator runs on a new host -- four million seeded velocities
+    through the device kernel and through the host's own atan2f / sinf / cosf, no mismatch on the hosts this was built for"""
+    bad, where = ctypes.c_uint64(123), (ctypes.c_float * 2)()
+    assert nb.load().nb_selftest_matrices(1 << 22, 2024, ctypes.byref(bad), where) == 0, nb._lib.last_error()
+    assert bad.value == 0, f"{bad.value} matrices differ from the host libm's, e.g. for velocity ({where[0]!r}, {where[1]!r})"
+    assert nb.load().nb_selftest_matrices(0, 1, ctypes.byref(bad), None) == nb._lib.NB_ERR_INVALID
