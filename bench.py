@@ -55,6 +55,37 @@ def executed_ops(mode, data, kernel):
     return EXECUTED_OPS.get((mode, data, kernel), EXECUTED_OPS[(mode, data)])
 
 
+def roofline_fractions(mode, data, form, n, count, kernel_ms):
+    """What one launch of kernel form `form` over `count` of `n` bodies achieves against the fp32 vector roofline, every figure saying
+    what it divides.  Pure arithmetic (tests/test_bench_math.py).
+
+    Pair EVALUATIONS a launch executes: the ordered folds evaluate every ordered pair the reference does (count x n, self pairs
+    included).  The pairs forms evaluate an unordered pair ONCE for both bodies: a whole set n^2 / 2 + superblock / 2 x n (the pairs
+    between superblocks once, the pairs inside them as an ordered fold; superblocks of 2 048 bodies from 131 072 bodies on, nb_api.hip:
+    make_plan); a rank of the multi-GPU form count x n / 2 + 256 count (its blocks against the half of the ring behind them + each
+    block of 512 against itself).
+      achieved / frac          18 flop x the evaluations EXECUTED / time (/ the spec peak): can never pass 1
+      achieved_nominal / frac_nominal   18 flop x the reference's count x n ordered pairs / time: what the work is worth in the
+                               reference's own count; passes 1 where one evaluation serves two bodies
+      frac_executed            vector lane operations per second (full-rate ops + reciprocals per ordered pair of the reference)
+                               over the spec issue rate of one per lane per cycle"""
+    kernel_s = kernel_ms * 1e-3
+    nominal = FLOP_PER_INTERACTION * count * n / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    ex = dict(executed_ops(mode, data, "step_fast_pairs_kernel" if form == "step_fast_ring_kernel" else form))
+    if form == "step_fast_pairs_kernel":
+        superblock = 2048.0 if n >= 131072 and n % 512 == 0 else 1024.0
+        evaluations = float(n) * n / 2.0 + superblock / 2.0 * n
+    elif form == "step_fast_ring_kernel":
+        evaluations = float(count) * n / 2.0 + 256.0 * count
+    else:
+        evaluations = float(count) * n
+    achieved = FLOP_PER_INTERACTION * evaluations / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    lane_ops = (ex["full_rate_ops"] + ex["v_rcp_f32"]) * float(count) * n / kernel_s if kernel_s > 0 else 0.0
+    return {"achieved": achieved, "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "achieved_nominal": nominal,
+            "frac_nominal": nominal / PEAK_FP32_VECTOR_TFLOPS, "lane_ops_per_s": lane_ops, "frac_executed": lane_ops / SPEC_LANE_OPS_PER_S,
+            "pair_evaluations_per_launch": evaluations, "executed_per_interaction": ex}
+
+
 def committed_traffic(nb, kernels, n, count):
     """HBM bytes per step from the committed rocprofv3 --pmc passes (tools/pmc_summary.py --json), or (None, why).
 
@@ -242,22 +273,8 @@ def main():
     def summarise(r, data="planar"):
         steps_per_s = r["steps"] / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
-        nominal = FLOP_PER_INTERACTION * r["count"] * r["n"] / kernel_s / 1e12 if kernel_s > 0 else 0.0
-        # Pair EVALUATIONS a launch executes.  The ordered folds evaluate every ordered pair the reference does (count x n, self
-        # pairs included).  The pairs forms evaluate an unordered pair ONCE for both bodies: a whole set n^2 / 2 + 1 024 n (the pairs
-        # between superblocks of 2 048 bodies once, the pairs inside them as an ordered fold); a rank of the multi-GPU form
-        # count x n / 2 + 256 count (its blocks against the half of the ring behind them + each block of 512 against itself).
-        form = r["kernels"][0]
-        ex = dict(executed_ops(r["mode"], data, "step_fast_pairs_kernel" if form == "step_fast_ring_kernel" else form))
-        if form == "step_fast_pairs_kernel":
-            superblock = 2048.0 if r["n"] >= 131072 and r["n"] % 512 == 0 else 1024.0   # (nb_api.hip:make_plan)
-            evaluations = float(r["n"]) * r["n"] / 2.0 + superblock / 2.0 * r["n"]
-        elif form == "step_fast_ring_kernel":
-            evaluations = float(r["count"]) * r["n"] / 2.0 + 256.0 * r["count"]
-        else:
-            evaluations = float(r["count"]) * r["n"]
-        achieved = FLOP_PER_INTERACTION * evaluations / kernel_s / 1e12 if kernel_s > 0 else 0.0
-        lane_ops = (ex["full_rate_ops"] + ex["v_rcp_f32"]) * float(r["count"]) * r["n"] / kernel_s if kernel_s > 0 else 0.0
+        fr = roofline_fractions(r["mode"], data, r["kernels"][0], r["n"], r["count"], r["kernel_ms"])
+        nominal, evaluations, achieved, lane_ops, ex = fr["achieved_nominal"], fr["pair_evaluations_per_launch"], fr["achieved"], fr["lane_ops_per_s"], fr["executed_per_interaction"]
         traffic, source = committed_traffic(nb, r["kernels"], r["n"], r["count"])
         roof = {"bound": "fp32_valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,

@@ -1,0 +1,57 @@
+"""bench.py's roofline arithmetic, on the CPU: every printed fraction must mean what it says.  The kernel
+times fed in are the ones measured in profiles/r03 and profiles/r04."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the parent part of bench.py imports neither torch nor the library)
+
+N = 131072
+
+
+def test_ordered_folds_price_every_ordered_pair():
+    r = bench.roofline_fractions("strict", "planar", "step_strict_sl_kernel", N, N, 5.491)
+    assert r["pair_evaluations_per_launch"] == float(N) * N
+    assert r["frac"] == r["frac_nominal"] == pytest.approx(18 * N * N / 5.491e-3 / 1e12 / 157.3)
+    assert r["frac"] == pytest.approx(0.358, abs=2e-3)
+    # 18 full-rate operations + one reciprocal per pair: lane operations per second over 256 CUs x 128 lanes x 2.4 GHz
+    assert r["frac_executed"] == pytest.approx(19 * N * N / 5.491e-3 / (256 * 128 * 2.4e9), rel=1e-3)   # (157.3 TFLOP/s / 2)
+    assert 0.7 < r["frac_executed"] < 0.8
+    shard = bench.roofline_fractions("strict", "planar", "step_strict_bc_kernel", N, N // 8, 0.789)
+    assert shard["pair_evaluations_per_launch"] == float(N // 8) * N and shard["frac"] == pytest.approx(0.3113, abs=2e-3)
+
+
+def test_the_pairs_form_is_priced_on_what_it_executes():
+    r = bench.roofline_fractions("fast", "planar", "step_fast_pairs_kernel", N, N, 1.669)
+    # every unordered pair of two superblocks once, the pairs inside the 64 superblocks of 2 048 bodies as an ordered fold
+    assert r["pair_evaluations_per_launch"] == N * N / 2 + 1024 * N
+    assert r["frac"] < 1.0 and r["frac"] == pytest.approx(0.598, abs=3e-3)          # round 3 printed 1.18 under this name
+    assert r["frac_nominal"] == pytest.approx(1.178, abs=3e-3) and r["frac_nominal"] > 1.0
+    assert r["frac_nominal"] / r["frac"] == pytest.approx(N * N / (N * N / 2 + 1024 * N))
+    assert r["frac_executed"] == pytest.approx(5.25 * N * N / 1.669e-3 / 7.8643e13, rel=1e-3) and r["frac_executed"] < 1.0
+    small = bench.roofline_fractions("fast", "planar", "step_fast_pairs_kernel", 65536, 65536, 0.5)
+    assert small["pair_evaluations_per_launch"] == 65536 * 65536 / 2 + 512 * 65536        # superblocks of 1 024 bodies below 131 072
+
+
+def test_a_rank_of_the_ring_is_priced_on_its_own_evaluations():
+    count = N // 8
+    r = bench.roofline_fractions("fast", "planar", "step_fast_ring_kernel", N, count, 0.229)
+    assert r["pair_evaluations_per_launch"] == count * N / 2 + 256 * count
+    assert r["frac"] < 1.0 and r["frac_nominal"] == pytest.approx(18 * count * N / 0.229e-3 / 1e12 / 157.3)
+    assert r["frac"] == pytest.approx(r["frac_nominal"] * (count * N / 2 + 256 * count) / (count * N))
+    assert r["executed_per_interaction"]["full_rate_ops"] == 5.0
+
+
+def test_three_d_data_has_its_own_operation_counts():
+    assert bench.roofline_fractions("strict", "3d", "step_strict_sl_kernel", N, N, 7.8)["executed_per_interaction"]["full_rate_ops"] == 26
+    assert bench.roofline_fractions("fast", "3d", "step_fast_pairs_kernel", N, N, 2.2)["executed_per_interaction"]["full_rate_ops"] == 7.125
+    assert bench.roofline_fractions("fast", "planar", "step_fast_sl_kernel", N, N, 2.3)["frac"] == pytest.approx(0.855, abs=5e-3)
+
+
+def test_a_zero_kernel_time_does_not_divide():
+    r = bench.roofline_fractions("strict", "planar", "step_strict_sl_kernel", N, N, 0.0)
+    assert r["frac"] == r["frac_nominal"] == r["frac_executed"] == 0.0
