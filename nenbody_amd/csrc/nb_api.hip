@@ -48,7 +48,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, fast_pairs_side, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -95,7 +95,6 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->fast_pairs_w = read_knob("NB_FAST_PAIRS_W");
     d->fast_pairs_chunk = read_knob("NB_FAST_PAIRS_CHUNK");
     d->fast_pairs_np = read_knob("NB_FAST_PAIRS_NP");
-    d->fast_pairs_side = read_knob("NB_FAST_PAIRS_SIDE");
     d->inst_device_libm = read_knob("NB_INST_DEVICE_LIBM");
     d->ring = read_knob("NB_RING");
     d->ring_np = read_knob("NB_RING_NP");
@@ -144,7 +143,6 @@ struct Plan {
     uint32_t bc;                            // STRICT: 1 = block-chain form (nb_nbody_bc.inc) instead of producer/consumer; needs scratch
     uint32_t pairs;                         // FAST: the pairs form (nb_nbody_sym.inc: every unordered pair once; whole sets, n a multiple of 256; needs scratch) with this many waves per workgroup (8, 4, 2, 1); 0 = another form
     uint32_t pairs_np;                      // pairs form: packed pairs of bodies per lane, 2 or 4 (blocks of 256 or 512 bodies)
-    uint32_t pairs_side;                    // pairs form, one tile: 1 = the diagonal kernel on a low-priority side stream beside the sweep (NB_FAST_PAIRS_SIDE=0: in sequence)
     uint32_t pairs_chunk;                   // pairs form: bodies per chunk of the two-level walk (0: the default -- one tile up to 262 144 bodies, chunks of 131 072 beyond)
     uint32_t fsl;                           // FAST: 1 = scalar-load form (step_fast_sl_kernel, nb_nbody_sl.inc): whole-set launches, eight waves per workgroup; needs scratch
     uint32_t sl;                            // STRICT: 1 = scalar-load form (nb_nbody_sl.inc) instead of the LDS-tiled one-lane kernel; needs scratch
@@ -274,7 +272,6 @@ int make_plan(const nb_params &p, uint32_t n_total, uint32_t count, Plan *out, s
         pl.pairs = (pairs_ok && dbg.fast_pairs.or_else((n_total >= kPairsMinN && no_form_named && !dbg.fast_sl.set && !dbg.fast_ib.set &&
                                                         !dbg.fast_slices.set) ? 1u : 0u)) ? pw : 0u;
         pl.pairs_np = pnp;
-        pl.pairs_side = dbg.fast_pairs_side.or_else(1u) ? 1u : 0u;
         pl.pairs_chunk = 0;
         if (pl.pairs && dbg.fast_pairs_chunk.on()) {  // whole superblocks per chunk
             const uint32_t super = 128u * pnp * pw;
@@ -566,7 +563,6 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
     a.no_packed = pl.no_packed;
     a.spin_budget = pl.spin_budget;
     a.bc_prio = pl.bc_prio;
-    a.pairs_side = pl.pairs_side;
     a.j_count = n_total;  // the whole set: no base, no hole
     a.j_base = 0;
     a.hole_lo = 0xffffffffu;
@@ -1904,7 +1900,6 @@ NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double sec
                 a.force_3d = pl.force_3d;
                 a.j_chunk = pl.j_chunk;
                 a.no_packed = pl.no_packed;
-                a.pairs_side = pl.pairs_side;
                 a.hole_lo = 0xffffffffu;
                 a.stamps = stamps;
                 e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, c->scratch, c->stream)

@@ -26,7 +26,6 @@ struct StepArgs {
     uint32_t j_count, j_base, hole_lo, hole_len;
     uint32_t partial_row0;      // FAST: first row of a.partial this launch writes
     uint32_t always_partial;    // FAST: 1 = write partial sums even when gridDim.y == 1 (a later launch integrates)
-    uint32_t pairs_side;        // FAST pairs form, host side only: 1 = the diagonal kernel on a low-priority side stream beside the sweep
     // Diagnostic (nb_diag_step_clock only; NULL in every product launch): the first wave of each workgroup of the whole-set
     // kernels stores (s_memtime, s_memrealtime) at entry and exit, 4 words per workgroup: the clock the part holds under
     // THIS kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz.  No output depends on it.
