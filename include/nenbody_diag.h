@@ -37,6 +37,12 @@ int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations);
  * nb_launch_instances and through the host's atan2f / sinf / cosf: *mismatches = matrices whose rotation entries differ in some
  * bit (0 on the hosts the library was built for); bad_velocity (may be NULL) receives one offending (x, y). */
 int nb_selftest_matrices(uint32_t count, uint64_t seed, uint64_t *mismatches, float *bad_velocity);
+/* The same question function by function and argument by argument: fn = 0 sinf, 1 cosf, 2 atanf, 3 atan2f(y = the argument,
+ * x = the binary32 with bit pattern x_bits), over `count` consecutive binary32 bit patterns from `first` (first = 0, count = 0: all
+ * 2^32) -- the device's restatement against the host's std::sin / cos / atan / atan2, NaN results equal whatever their payload.
+ * *mismatches: how many differ; first_bad (may be NULL): the lowest differing bit pattern.  All 2^32 arguments of one function take
+ * about a minute (the host side is the slower one). */
+int nb_selftest_libm(int fn, uint32_t first, uint64_t count, uint32_t x_bits, uint64_t *mismatches, uint32_t *first_bad);
 
 /* Diagnostic: what the vector ALU of THIS device issues at the clock it holds under load -- a register-only stream of
  * independent instructions on every SIMD (8 waves each) for about `seconds` (<= 2), in lane-operations per second.

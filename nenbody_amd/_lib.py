@@ -147,6 +147,7 @@ DIAG_PROTOTYPES = {
     "nb_selftest_ladder": (c_int, [c_uint32, c_uint32, POINTER(c_uint64), c_void_p]),
     "nb_selftest_rcp_scaling": (c_int, [c_int, c_int, POINTER(c_uint64)]),
     "nb_selftest_matrices": (c_int, [c_uint32, c_uint64, POINTER(c_uint64), c_void_p]),
+    "nb_selftest_libm": (c_int, [c_int, c_uint32, c_uint64, c_uint32, POINTER(c_uint64), POINTER(c_uint32)]),
     "nb_selftest_divide": (c_int, [POINTER(NbParams), c_uint64, c_uint64, POINTER(c_uint64), c_void_p]),
     "nb_selftest_valu_rate": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "nb_diag_step_clock": (c_int, [POINTER(NbParams), c_uint32, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double),

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nenbody.h"
@@ -1727,6 +1728,67 @@ NB_EXPORT int nb_selftest_matrices(uint32_t count, uint64_t seed, uint64_t *mism
         }
     }
     *mismatches = bad;
+    return NB_OK;
+}
+
+// The device's atan2f / sinf / cosf / atanf (nb_libm.h) against THIS host's C library, argument by argument: `count` consecutive
+// binary32 bit patterns from `first` (count = 0 with first = 0: all 2^32) through function fn -- 0 sinf, 1 cosf, 2 atanf, 3
+// atan2f(y = the argument, x = the float with bit pattern x_bits) -- on the device in chunks of 2^24 and through std::sin / cos /
+// atan / atan2 on `threads` host threads; NaN results compare equal whatever their payload.  All of sinf takes about a minute.
+NB_EXPORT int nb_selftest_libm(int fn, uint32_t first, uint64_t count, uint32_t x_bits, uint64_t *mismatches, uint32_t *first_bad)
+{
+    if (!mismatches || fn < 0 || fn > 3 || count > (1ull << 32) || (uint64_t)first + count > (1ull << 32)) {
+        g_tls_error = "nb_selftest_libm: need mismatches != NULL, fn in 0..3 and first + count <= 2^32";
+        return NB_ERR_INVALID;
+    }
+    if (count == 0 && first == 0) count = 1ull << 32;
+    int rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    constexpr uint32_t kChunk = 1u << 24;
+    uint32_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)kChunk * sizeof(uint32_t));
+    std::vector<uint32_t> got(kChunk);
+    const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::atomic<uint64_t> bad{0};
+    std::atomic<uint64_t> where{~0ull};
+    float xo;
+    std::memcpy(&xo, &x_bits, 4);
+    for (uint64_t done = 0; done < count && e == hipSuccess; done += kChunk) {
+        const uint32_t base = (uint32_t)(first + done), m = (uint32_t)std::min<uint64_t>(kChunk, count - done);
+        e = nbk::launch_libm_selftest(fn, base, m, x_bits, d_out, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(got.data(), d_out, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) break;
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                uint64_t mine = 0;
+                for (uint32_t i = t; i < m; i += threads) {
+                    const uint32_t u = base + i;
+                    float x, r;
+                    std::memcpy(&x, &u, 4);
+                    r = fn == 0 ? std::sin(x) : fn == 1 ? std::cos(x) : fn == 2 ? std::atan(x) : std::atan2(x, xo);
+                    uint32_t rb;
+                    std::memcpy(&rb, &r, 4);
+                    float g;
+                    std::memcpy(&g, &got[i], 4);
+                    if (rb != got[i] && !(r != r && g != g)) {
+                        ++mine;
+                        uint64_t cur = where.load();
+                        while ((uint64_t)u < cur && !where.compare_exchange_weak(cur, (uint64_t)u)) {
+                        }
+                    }
+                }
+                bad += mine;
+            });
+        for (auto &th : pool) th.join();
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) {
+        g_tls_error = std::string("nb_selftest_libm: ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    *mismatches = bad.load();
+    if (first_bad) *first_bad = where.load() == ~0ull ? 0u : (uint32_t)where.load();
     return NB_OK;
 }
 

@@ -124,6 +124,8 @@ hipError_t launch_ladder_exhaustive(uint32_t first_md, uint32_t count_md, bool c
                                     hipStream_t s);
 // v_rcp_f32(m * 2^k) * 2^k == v_rcp_f32(m) for all 2^23 significands m and k in [k_lo, k_hi]
 hipError_t launch_rcp_scaling(int k_lo, int k_hi, unsigned long long *violations, hipStream_t s);
+// nb_libm.h evaluated on the device: out[i] = bits of fn(float with bit pattern first + i) (0 sinf, 1 cosf, 2 atanf, 3 atan2f(., x = bits `other`))
+hipError_t launch_libm_selftest(int fn, uint32_t first, uint32_t count, uint32_t other, uint32_t *out, hipStream_t s);
 // `blocks` workgroups of 256 lanes each issue trips * 64 register-only vector instructions per lane (mix 0: v_fma_f32; 1: the folds' mix)
 // mix 3 / 4: v_fma_f32 / v_fmac_f32 with DISTINCT source registers per chain (mix 0 shares two sources among all eight chains).
 // stamps (may be NULL): 4 words per workgroup, (s_memtime, s_memrealtime) at entry and exit of its first wave

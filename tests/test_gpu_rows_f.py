@@ -227,3 +227,25 @@ def test_library_selftest_of_the_matrices_against_the_host_libm(nb):
     assert nb.load().nb_selftest_matrices(1 << 22, 2024, ctypes.byref(bad), where) == 0, nb._lib.last_error()
     assert bad.value == 0, f"{bad.value} matrices differ from the host libm's, e.g. for velocity ({where[0]!r}, {where[1]!r})"
     assert nb.load().nb_selftest_matrices(0, 1, ctypes.byref(bad), None) == nb._lib.NB_ERR_INVALID
+
+
+def test_device_libm_equals_the_host_libm_argument_by_argument(nb):
+    """nb_selftest_libm: the device's restated sinf / cosf / atanf / atan2f against the host's, over windows of consecutive
+    bit patterns that cover every branch -- around 0, the subnormals, 2^-12 and 2^-29 (the "return x" cut-offs), pi/4, 1, the
+    reduction switch at 120, 2^25, infinity and NaN, both signs.  (tools/libm_device.py runs all 2^32 arguments of each:
+    profiles/r04/libm_device.log.)"""
+    lib = nb.load()
+    bad, where = ctypes.c_uint64(), ctypes.c_uint32()
+    windows = [0x00000000, 0x007ff000, 0x30fff000, 0x397ff000, 0x3ee00000 - 0x800, 0x3f300000 - 0x800, 0x3f490000, 0x3f7ff800,
+               0x3f980000 - 0x800, 0x401c0000 - 0x800, 0x42effc00, 0x4bfff800, 0x7f7ff000]
+    for fn in (0, 1, 2):
+        for w in windows:
+            for sign in (0, 0x80000000):
+                assert lib.nb_selftest_libm(fn, w | sign, 1 << 13, 0, ctypes.byref(bad), ctypes.byref(where)) == 0
+                assert bad.value == 0, f"fn {fn}: {bad.value} mismatches from 0x{(w | sign):08x}, first 0x{where.value:08x}"
+        assert lib.nb_selftest_libm(fn, 0x3f000000, 1 << 24, 0, ctypes.byref(bad), ctypes.byref(where)) == 0 and bad.value == 0   # [0.5, 2)
+    for xb in (0x3f800000, 0xbf000000, 0x3dcccccd, 0x00000000, 0x7f800000):
+        for w in (0x00000000, 0x3d000000, 0x3f000000, 0x42000000, 0x7f7ff000, 0xbd000000, 0xbf000000):
+            assert lib.nb_selftest_libm(3, w, 1 << 16, xb, ctypes.byref(bad), ctypes.byref(where)) == 0
+            assert bad.value == 0, f"atan2f(y from 0x{w:08x}, x = 0x{xb:08x}): first bad y 0x{where.value:08x}"
+    assert lib.nb_selftest_libm(7, 0, 1, 0, ctypes.byref(bad), None) == nb._lib.NB_ERR_INVALID
