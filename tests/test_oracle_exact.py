@@ -209,3 +209,46 @@ def test_boids_oracle_equals_exact_rational_ieee_arithmetic(oracle, n, k, seed, 
     p_ref, v_ref = boids_exact(pos, vel, 1, r1=400.0, r2=3.0, r3=1.5)
     p, v = oracle.boids_run(pos, vel, 1, bp)
     assert (bits(p) == bits(p_ref)).all() and (bits(v) == bits(v_ref)).all()
+
+
+# ---- CameraArray::update (src/gfx.rs:397-408, build_camera :358-369): cp * look_at_dir(eye, dir, up), by hand ------------------
+def cameras_exact(eyes, dirs, up, cp):
+    up = [to_frac(c) for c in up]
+    cpf = [[to_frac(c) for c in col] for col in cp]                       # cpf[k] = column k
+
+    def normalize(v):                                                      # self * (1 / magnitude)
+        sq = [rnd(c * c) for c in v]
+        mag = sqrt_rnd(rnd(rnd(sq[0] + sq[1]) + sq[2]))
+        s = rnd(Fraction(1) / mag)
+        return [rnd(c * s) for c in v]
+
+    def cross(a, b):
+        return [rnd(rnd(a[1] * b[2]) - rnd(a[2] * b[1])), rnd(rnd(a[2] * b[0]) - rnd(a[0] * b[2])), rnd(rnd(a[0] * b[1]) - rnd(a[1] * b[0]))]
+
+    def dot(a, b):
+        return rnd(rnd(rnd(a[0] * b[0]) + rnd(a[1] * b[1])) + rnd(a[2] * b[2]))
+
+    out = []
+    for eye, d in zip(eyes, dirs):
+        eye, f = [to_frac(c) for c in eye], normalize([to_frac(c) for c in d])
+        s = normalize(cross(f, up))
+        u = cross(s, f)
+        view = [[s[0], u[0], -f[0], Fraction(0)], [s[1], u[1], -f[1], Fraction(0)], [s[2], u[2], -f[2], Fraction(0)],
+                [-dot(eye, s), -dot(eye, u), dot(eye, f), Fraction(1)]]
+        m = [[rnd(rnd(rnd(rnd(cpf[0][e] * view[k][0]) + rnd(cpf[1][e] * view[k][1])) + rnd(cpf[2][e] * view[k][2])) + rnd(cpf[3][e] * view[k][3]))
+              for e in range(4)] for k in range(4)]
+        out.append([[to_f32(c) for c in col] for col in m])
+    return np.array(out, np.float32)
+
+
+def test_cameras_oracle_equals_exact_rational_ieee_arithmetic(oracle):
+    n = 40
+    pos, vel = oracle.init_state(n, 11)
+    rng = np.random.default_rng(11)
+    pos[:, 2] = rng.uniform(-5, 5, n).astype(np.float32)
+    vel[:, 2] = rng.uniform(-0.05, 0.05, n).astype(np.float32)
+    up = np.array([0, 0, 1], np.float32)
+    cp = oracle.camera_constant(30.0, 1.5)
+    got = oracle.cameras(pos, vel, up, cp)
+    ref = cameras_exact(pos, vel, up, np.asarray(cp, np.float32).reshape(4, 4))
+    assert (bits(got) == bits(ref)).all()
