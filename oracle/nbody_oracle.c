@@ -8,8 +8,12 @@
  * PARITY UNPINNED: the reference (Rust) cannot be compiled in this environment
  * (no cargo/rustc) and ships no tests, golden vectors or fixtures for this path
  * (SURVEY.md section 4 / 8c).  This file restates src/main.rs:404-441 operation by
- * operation; it is cross-checked by an independent numpy float32 restatement and by
- * hand-derived known-answer tests (tests/test_oracle.py), nothing stronger.
+ * operation; it is cross-checked by an independent numpy float32 restatement, by
+ * hand-derived known-answer tests (tests/test_oracle.py) and -- what "every operation
+ * rounded once to binary32, in the reference's order" MEANS, independently of this
+ * compiler and FPU -- by the same steps in exact rational arithmetic with the rounding
+ * done by hand (tests/test_oracle_exact.py: n-body, boids, cameras).  None of that is the
+ * Rust original's own output: parity with the reference stays unpinned.
  *
  * The arithmetic lives in the third-party crate cgmath 0.17.0 (Cargo.toml:16,
  * Cargo.lock:177-185), which is not vendored under /root/reference.  Its published
