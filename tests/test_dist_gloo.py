@@ -81,7 +81,7 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=F
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 64, 5), (2, 37, 4), (3, 50, 3)])
+@pytest.mark.parametrize("world,n,k", [(2, 64, 5), (2, 37, 4), (3, 50, 3), (8, 70, 2)])
 def test_sharded_equals_unsharded(tmp_path, oracle, world, n, k):
     mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path)), nprocs=world, join=True)
     pos, vel = oracle.init_state(n, seed=4321)
@@ -145,7 +145,7 @@ def test_sharded_fast_with_overlapped_exchange(tmp_path, oracle, world, n, k):
     assert not sc.overlap
 
 
-@pytest.mark.parametrize("world,n,k,partners", [(2, 64, 4, 1), (3, 48, 3, 2), (3, 51, 3, 2), (4, 64, 3, 2)])
+@pytest.mark.parametrize("world,n,k,partners", [(2, 64, 4, 1), (3, 48, 3, 2), (3, 51, 3, 2), (4, 64, 3, 2), (8, 64, 2, 4), (5, 55, 2, 3)])
 def test_sharded_fast_pairs_once_with_second_exchange(tmp_path, oracle, world, n, k, partners):
     """ring=True (FAST, equal ranks): every unordered pair is evaluated once, by the rank that owns the body further back on the
     ring of indices; the other body's half travels to its owner in a second, point-to-point exchange (nb_launch_ring_fold /
