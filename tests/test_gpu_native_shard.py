@@ -342,3 +342,84 @@ def test_rccl_leg_of_the_pairs_form_on_a_one_rank_communicator(nb, oracle):
     assert np.isfinite(p).all() and np.isfinite(v).all()
     assert (p[16384:] == pos[16384:]).all()          # the other ranks' slots: nothing arrived, nothing was touched
     assert np.abs(p[:16384] - pos[:16384]).max() > 0
+
+
+@pytest.mark.parametrize("mode_name", ["strict", "fast"])
+def test_eight_ranks_as_threads_of_one_process(nb, oracle, mode_name):
+    """EIGHT ranks -- the world of BASELINE.json's configs 4 and 5 -- as eight threads of this process, each with its own native
+    shard and stream on the one GPU ("one process (or thread) per GPU"), both exchanges supplied by the
+    host through a barrier: nb_shard_step's indexing at the world size the 8-GPU node will run (D = 4 partners of the pairs form,
+    the antipodal rank among them), and the library's per-thread plan caches under eight concurrent callers.  STRICT: every
+    rank's bits equal the oracle's; FAST: the pairs form, two exchanges per step, within FAST's tolerance."""
+    import threading
+
+    world, n, steps = 8, 32768, 2
+    mode = nb.NB_MODE_STRICT if mode_name == "strict" else nb.NB_MODE_FAST
+    pos, vel = oracle.init_state(n, 77)
+    nb.load()
+    hip = _hip_runtime()
+    barrier = threading.Barrier(world, timeout=120)
+    slots, halves, calls, results, errors = {}, {}, {"gather": 0, "ring": 0}, {}, []
+    mu = threading.Lock()
+
+    def rank_thread(rank):
+        def gather(buf, slot_bytes, rank_, world_, stream):
+            assert (rank_, world_) == (rank, world)
+            assert hip.hipStreamSynchronize(stream) == 0
+            mine = np.empty(slot_bytes, np.uint8)
+            assert hip.hipMemcpy(mine.ctypes.data, buf + rank * slot_bytes, slot_bytes, 2) == 0
+            slots[rank] = mine
+            barrier.wait()
+            full = np.concatenate([slots[r] for r in range(world)])
+            assert hip.hipMemcpy(buf, full.ctypes.data, world * slot_bytes, 1) == 0
+            barrier.wait()   # nobody replaces its slot before everyone has read it
+            with mu:
+                calls["gather"] += 1
+
+        def ring(send, recv, chunk_bytes, partners, rank_, world_, stream):
+            assert (rank_, world_, partners) == (rank, world, 4)
+            assert hip.hipStreamSynchronize(stream) == 0
+            out = np.empty(partners * chunk_bytes, np.uint8)
+            assert hip.hipMemcpy(out.ctypes.data, send, partners * chunk_bytes, 2) == 0
+            halves[rank] = out
+            barrier.wait()
+            got = np.concatenate([halves[(rank - d) % world][(d - 1) * chunk_bytes:d * chunk_bytes] for d in range(1, partners + 1)])
+            assert hip.hipMemcpy(recv, got.ctypes.data, partners * chunk_bytes, 1) == 0
+            barrier.wait()
+            with mu:
+                calls["ring"] += 1
+
+        try:
+            with nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=rank, world=world, gather=gather,
+                                ring=ring if mode == nb.NB_MODE_FAST else None) as sh:
+                partners = sh.partners
+                sh.step(steps)
+                sh.sync()
+                results[rank] = (sh.first, sh.count, partners, sh.positions(), sh.local_velocities(), sh.local_instances())
+        except Exception as e:  # a rank that fails must not leave the others at the barrier
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_thread, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert sorted(results) == list(range(world))
+    p_ref, v_ref = oracle.run(pos, vel, steps)
+    inst_ref = oracle.instances(p_ref, v_ref)
+    assert calls["gather"] == world * steps and calls["ring"] == (world * steps if mode == nb.NB_MODE_FAST else 0)
+    scale = float(np.abs(v_ref - vel).max())
+    for r in range(world):
+        first, count, partners, p, v, inst = results[r]
+        assert (first, count) == nb.partition(n, world)[r] and partners == (4 if mode == nb.NB_MODE_FAST else 0)
+        if mode == nb.NB_MODE_STRICT:
+            assert_bits_equal(p, p_ref, f"rank {r} positions (replica)")
+            assert_bits_equal(v, v_ref[first:first + count], f"rank {r} velocities")
+            assert matrices_equal(inst, inst_ref[first:first + count])
+        else:
+            dv = np.abs(v - v_ref[first:first + count]).max(axis=1)
+            assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r}: {np.quantile(dv, 0.999) / scale:.2e} {dv.max() / scale:.2e}"
+            dp = np.abs(p - p_ref).max(axis=1)
+            assert np.quantile(dp, 0.999) <= 2e-4 * scale and dp.max() <= 2e-2 * scale, f"rank {r} positions (replica)"
