@@ -55,6 +55,27 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     assert line["boids_controller"]["split_form"]["value"] > 0
 
 
+@pytest.mark.gpu
+def test_gpus_4_mode_fast_rehearsal_takes_the_pairs_form_as_the_headline():
+    """`bench.py --gpus 4 --mode fast` on the one GPU of the test box: four ranks share the device, both of the
+    step's exchanges go through gloo -- the all-gather and the point-to-point one to the TWO ranks in front.  The headline of that
+    line is the pairs form on shards; no scaling number is claimed."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--mode", "fast", "--steps", "2", "--warmup", "1", "--preheat-ms", "20",
+                        "--no-cpu-baseline", "--no-secondary"],
+                       env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and "REHEARSAL" in line["data"] and line["config"]["mode"] == "fast"
+    assert line["roofline"]["kernel"] == "step_fast_ring_kernel" and "step_fast_ring_kernel" in line["roofline"]["kernels_per_step"][0]
+    assert "2 ranks in front" in line["config"]["sharding"]
+    # a rank's launch evaluates N^2 / (2 x 4) unordered pairs (+ its blocks' inner pairs once more): frac prices those, frac_nominal N^2 / 4
+    n = 131072
+    assert 0.95 < line["roofline"]["pair_evaluations_per_launch"] / (n * n / 8) < 1.05
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["frac_nominal"] > 1.8 * line["roofline"]["frac"]
+
+
 def _preheat_rank(rank, world, port, out_dir):
     import time
 
