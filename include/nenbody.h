@@ -237,7 +237,8 @@ int nb_launch_step_phase(const nb_params *params, uint32_t n_total, uint32_t fir
  *                          pos_out[first, first + count) and vel (count records) as nb_launch_step writes them.
  * Every order of addition is fixed (run-to-run identical); FAST only (reassociated sums; STRICT shards keep nb_launch_step).
  * nb_ring_partners: D >= 1; 0 when this shape does not take the form (STRICT, unequal or partial ranks, count not a multiple of
- * 256, a set below 32 768 bodies: use nb_launch_step); or a negative nb_status.  Every rank of a job gets the same answer. */
+ * 256, or fewer than 2^30 ordered pairs per rank and step -- n_total x count -- where what the form saves no longer pays for its
+ * second exchange: use nb_launch_step); or a negative nb_status.  Every rank of a job gets the same answer. */
 int nb_ring_partners(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
 size_t nb_ring_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
 int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *sums,

@@ -2261,15 +2261,19 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
 
 // ---- FAST on shards, every unordered pair once ("half shell", nb_nbody_ring.inc) ------------------------------------------
 namespace {
+constexpr uint64_t kRingMinPairs = 1ull << 30;  // ordered pairs of a rank's step from which the form is taken by itself
 struct RingPlan {
     Plan base;      // the sharing verdict (force_ieee), force_3d
     uint32_t np;    // packed pairs of bodies per lane: 4 (blocks of 512) where the shard is whole blocks of 512, else 2 (256)
     uint32_t ga, wpb;
     uint32_t partners;  // 0: this shape does not take the form
 };
-// Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and a set large enough that the
-// rows and the second exchange pay (the same line as the one-GPU pairs form: 32 768 bodies).  NB_RING=0/1 decides outright
-// where the shape allows it; NB_RING_NP / NB_RING_GA / NB_RING_WPB name the kernel's shape (tests, tools/).
+// Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and enough pairs per rank that what
+// the form saves pays for its second exchange: against the ordered fold of the same shard it saves n_total x count / 3e7 us
+// (profiles/r04/ring_times.log, ring_small.log: 15 us at 65 536 x 8 192, 26 at 65 536 x 16 384, 73 at 131 072 x 16 384; nothing at
+// 32 768 bodies on 4 or 8 ranks), the second exchange costs 17-23 us on a communicator of one (profiles/r04/step_overhead.log):
+// the line is n_total x count >= 2^30.  NB_RING=0/1 decides outright where the shape allows it; NB_RING_NP / NB_RING_GA /
+// NB_RING_WPB name the kernel's shape (tests, tools/).
 int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, RingPlan *out, std::string *err)
 {
     int rc = make_plan(p, n_total, count, &out->base, err);
@@ -2281,7 +2285,7 @@ int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_
     out->ga = dbg.ring_ga.or_else(0u);
     out->wpb = dbg.ring_wpb.or_else(0u) & ~3u;
     if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
-    if (!dbg.ring.or_else(n_total >= 32768u ? 1u : 0u)) return NB_OK;
+    if (!dbg.ring.or_else((uint64_t)n_total * count >= kRingMinPairs ? 1u : 0u)) return NB_OK;
     out->partners = nbk::ring_partners(n_total, first, count, out->np);
     return NB_OK;
 }

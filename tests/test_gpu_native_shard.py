@@ -149,7 +149,7 @@ def _hip_runtime():
     return hip
 
 
-def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None):
+def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None, force_pairs=False):
     import sys
 
     from conftest import ROOT
@@ -166,6 +166,9 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
         import oracle
 
         nenbody_amd.load()   # brings the HIP runtime into the global symbol scope
+        if force_pairs:   # below the library's own line (2^30 ordered pairs per rank and step) the pairs form is a test knob
+            os.environ["NB_RING"] = "1"
+            nenbody_amd.reload_env()
         hip = _hip_runtime()
         calls = []
 
@@ -278,7 +281,7 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(out), overlap, schedule, with_ring, 77), nprocs=world, join=True)
+        mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(out), overlap, schedule, with_ring, 77, True), nprocs=world, join=True)
         pos, vel = oracle.init_state(n, 77)
         p_ref, v_ref = reference(oracle, pos, vel, schedule)
         for r in range(world):
@@ -345,7 +348,7 @@ def test_rccl_leg_of_the_pairs_form_on_a_one_rank_communicator(nb, oracle):
 
 
 @pytest.mark.parametrize("mode_name", ["strict", "fast"])
-def test_eight_ranks_as_threads_of_one_process(nb, oracle, mode_name):
+def test_eight_ranks_as_threads_of_one_process(nb, oracle, monkeypatch, mode_name):
     """EIGHT ranks -- the world of BASELINE.json's configs 4 and 5 -- as eight threads of this process, each with its own native
     shard and stream on the one GPU ("one process (or thread) per GPU"), both exchanges supplied by the
     host through a barrier: nb_shard_step's indexing at the world size the 8-GPU node will run (D = 4 partners of the pairs form,
@@ -354,6 +357,7 @@ def test_eight_ranks_as_threads_of_one_process(nb, oracle, mode_name):
     import threading
 
     world, n, steps = 8, 32768, 2
+    monkeypatch.setenv("NB_RING", "1")   # (a set this small keeps the ordered fold by itself)
     mode = nb.NB_MODE_STRICT if mode_name == "strict" else nb.NB_MODE_FAST
     pos, vel = oracle.init_state(n, 77)
     nb.load()

@@ -162,6 +162,9 @@ def test_shapes_that_keep_the_ordered_fold(nb, monkeypatch):
     assert be.ring_partners(fast, 131072, 100, 16384) == 0          # not a rank of equal ranks
     assert be.ring_partners(fast, 131000, 0, 16375) == 0            # not whole blocks
     assert be.ring_partners(fast, 16384, 0, 2048) == 0              # small sets: the second exchange does not pay
+    # the line is 2^30 ordered pairs per rank and step (profiles/r04/ring_small.log)
+    assert be.ring_partners(fast, 65536, 0, 16384) == 2 and be.ring_partners(fast, 65536, 0, 8192) == 0
+    assert be.ring_partners(fast, 32768, 0, 16384) == 0 and be.ring_partners(fast, 65536, 0, 32768) == 1
     monkeypatch.setenv("NB_RING", "0")
     assert be.ring_partners(fast, 131072, 0, 16384) == 0
     assert be.ring_scratch_bytes(fast, 131072, 0, 16384) == 0
