@@ -67,7 +67,7 @@ int nb_diag_step_clock(const nb_params *params, uint32_t n, double seconds, doub
 /* Diagnostic: the NB_* environment variables -- kernel-form overrides the parity tests and tools/ use: NB_TILE, NB_FAST_IB,
  * NB_FAST_GROUPS, NB_FAST_WAVES, NB_FAST_SLICES, NB_FAST_NO_SHARE, NB_FAST_SL, NB_FAST_PAIRS / _W / _NP / _CHUNK, NB_RING / _NP / _GA /
  * _WPB, NB_FORCE_3D, NB_STRICT_LANES / _UNROLL / _PC / _BC / _SL / _NO_PACKED / _FORCE_IEEE, NB_BC_SPIN_BUDGET, NB_BC_PRIO,
- * NB_BOIDS_PC / _TILE / _FORCE, NB_INST_DEVICE_LIBM, NB_SELFTEST_CONTROL, NB_DROPIN_ZERO_COPY -- are NOT read by a process that
+ * NB_BOIDS_PC / _TILE / _FORCE, NB_INST_DEVICE_LIBM, NB_SELFTEST_CONTROL, NB_DROPIN_ZERO_COPY, NB_DROPIN_POLL -- are NOT read by a process that
  * merely loads the library: nothing a deployment's environment exports steers which kernels run.  nb_diag_enable_env(1) has
  * them read (now, and again at every nb_debug_reload_env()); nb_diag_enable_env(0) forgets them.  nb_debug_reload_env() alone
  * also switches the reading on (a test or tool that has just changed one calls it).  No launch path reads the environment;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -49,7 +50,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy, dropin_poll;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -108,6 +109,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_force = read_knob("NB_BOIDS_FORCE");
     d->boids_slices = read_knob("NB_BOIDS_SLICES");
     d->dropin_zero_copy = read_knob("NB_DROPIN_ZERO_COPY");
+    d->dropin_poll = read_knob("NB_DROPIN_POLL");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
     return d;
 }
@@ -829,6 +831,8 @@ struct nb_ctx {
     float *xfer = nullptr;    // 22n floats [matrices 16n | positions 3n | velocities 3n]: one-copy round trip of the drop-in calls
     float *hxfer = nullptr;   // its pinned host twin
     float *hxfer_dev = nullptr;  // the device's address of hxfer (mapped host memory: kernels of the small-set drop-in read and write it directly)
+    uint32_t *done_counter = nullptr;  // export_kernel's workgroup counter (ExportDone)
+    uint32_t done_seq = 0, polled_calls = 0;
     void *scratch = nullptr;
     StatusWord status;        // sticky failure word of this context's block-chain launches
     int cur = 0;
@@ -905,6 +909,7 @@ NB_EXPORT void nb_destroy(nb_ctx *ctx)
     if (ctx->cams) (void)hipFree(ctx->cams);
     if (ctx->xfer) (void)hipFree(ctx->xfer);
     if (ctx->hxfer) (void)hipHostFree(ctx->hxfer);
+    if (ctx->done_counter) (void)hipFree(ctx->done_counter);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->status.w) (void)hipFree(ctx->status.w);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -933,14 +938,64 @@ static int status_from_tail(nb_ctx *c, bool with_status)
     return check_status(&c->status, &c->err);  // reads it again, clears it, reports NB_ERR_STATE
 }
 
+// The smallest sets are ALL latency, the wait included: hipStreamSynchronize returns ~4 us after a kernel's last store has reached
+// the host (tools/ubench_sync.hip, profiles/r04/ubench_sync.log: 12.5 against 8.3 us for launch + wait of an empty kernel).  So
+// where the export kernel writes mapped host memory anyway, its last workgroup also writes a sequence number behind the
+// results and the host polls that word: per call 28.4 -> 24.4 us at N = 100, 52.8 -> 49.6 at 2 048 (profiles/r04/dropin_small.log).
+// Up to kPollMax bodies -- the reference's own ceiling (main.rs:653); from 4 096 bodies on the system-scope fences of the many
+// workgroups cost more than the wait saves (72.6 -> 77.3 us).  A word that does not arrive within kPollBudget falls back to the
+// stream wait, which also reports what went wrong.  NB_DROPIN_POLL=0: always the stream wait; =1: polled up to kZeroCopyMax.
+constexpr uint32_t kPollMax = 2048;
+constexpr size_t kDoneWordAt = 8;  // floats behind the 22n results (the status word is at 0)
+static bool small_set_poll(uint32_t n) { return small_set_zero_copy(n) && overrides().dropin_poll.or_else(n <= kPollMax ? 1u : 0u) != 0u; }
+
 static int ensure_xfer(nb_ctx *c)
 {
-    const size_t bytes = ((size_t)c->n * 22 + 16) * sizeof(float);  // + a tail word: the status word rides along (update_roundtrip)
+    const size_t bytes = ((size_t)c->n * 22 + 16) * sizeof(float);  // + a tail: the status word and the completion word ride along
     if (!c->xfer) NB_HIP(c, hipMalloc((void **)&c->xfer, bytes));
     if (!c->hxfer) {
         NB_HIP(c, hipHostMalloc((void **)&c->hxfer, bytes, hipHostMallocMapped));
         NB_HIP(c, hipHostGetDevicePointer((void **)&c->hxfer_dev, c->hxfer, 0));
+        std::memset(c->hxfer + 22 * (size_t)c->n, 0, 16 * sizeof(float));
     }
+    if (!c->done_counter) {
+        NB_HIP(c, hipMalloc((void **)&c->done_counter, sizeof(uint32_t)));
+        NB_HIP(c, hipMemset(c->done_counter, 0, sizeof(uint32_t)));
+    }
+    return NB_OK;
+}
+
+// what export_kernel is to signal for this call (nothing unless the set is polled)
+static nbk::ExportDone export_done(nb_ctx *c, bool polled)
+{
+    nbk::ExportDone d;
+    if (polled) {
+        d.counter = c->done_counter;
+        d.word = (uint32_t *)(c->hxfer_dev + 22 * (size_t)c->n + kDoneWordAt);
+        d.seq = ++c->done_seq ? c->done_seq : ++c->done_seq;  // never 0 (the word's initial value)
+    }
+    return d;
+}
+
+// waits for the export launched last: the polled word, or the stream
+static int wait_export(nb_ctx *c, const nbk::ExportDone &d)
+{
+    if (d.word) {
+        const volatile uint32_t *const w = (const volatile uint32_t *)(c->hxfer + 22 * (size_t)c->n + kDoneWordAt);
+        constexpr auto kPollBudget = std::chrono::milliseconds(2);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 1;; ++spins) {
+            if (*w == d.seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                // (now and then the runtime gets to see the stream idle: it retires its own bookkeeping at a wait)
+                if ((++c->polled_calls & 1023u) == 0u) NB_HIP(c, hipStreamSynchronize(c->stream));
+                return NB_OK;
+            }
+            if ((spins & 255u) == 0u && std::chrono::steady_clock::now() - t0 > kPollBudget) break;
+            __builtin_ia32_pause();
+        }
+    }
+    NB_HIP(c, hipStreamSynchronize(c->stream));
     return NB_OK;
 }
 
@@ -1227,15 +1282,17 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
         float *const dst = zero_copy ? ctx->hxfer_dev : ctx->xfer;
         // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait
         const bool with_status = ctx->status.dirty && ctx->status.w;
+        const nbk::ExportDone done = export_done(ctx, small_set_poll(ctx->n));
         NB_HIP(ctx, nbk::launch_export(ctx->n, ctx->pos[ctx->cur], ctx->vel, inst_16n ? (float4 *)dst : nullptr,
                                        pos_xyz ? dst + 16 * n : nullptr, vel_xyz ? dst + 19 * n : nullptr,
                                        with_status ? ctx->status.w : nullptr, with_status ? (uint32_t *)(dst + 22 * n) : nullptr, ctx->stream,
-                                       overrides().inst_device_libm.on() ? 1u : 0u));
+                                       overrides().inst_device_libm.on() ? 1u : 0u, done));
         if (!zero_copy) {
             const size_t lo = inst_16n ? 0 : (pos_xyz ? 16 * n : 19 * n), hi = with_status ? 22 * n + 1 : vel_xyz ? 22 * n : (pos_xyz ? 19 * n : 16 * n);
             NB_HIP(ctx, hipMemcpyAsync(ctx->hxfer + lo, ctx->xfer + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         }
-        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = wait_export(ctx, done);
+        if (rc != NB_OK) return rc;
         if (inst_16n) std::memcpy(inst_16n, ctx->hxfer, n * 16 * sizeof(float));
         if (pos_xyz) std::memcpy(pos_xyz, ctx->hxfer + 16 * n, bytes);
         if (vel_xyz) std::memcpy(vel_xyz, ctx->hxfer + 19 * n, bytes);
@@ -1373,11 +1430,13 @@ int update_roundtrip(nb_ctx *c, int kind, const nb_boids_params *bp, const float
     if (rc != NB_OK) return rc;
     // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait per frame
     const bool with_status = c->status.dirty && c->status.w;
+    const nbk::ExportDone done = export_done(c, small_set_poll(c->n));
     NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, with_status ? c->status.w : nullptr,
-                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream, overrides().inst_device_libm.on() ? 1u : 0u));
+                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream, overrides().inst_device_libm.on() ? 1u : 0u, done));
     if (!zero_copy)
         NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    NB_HIP(c, hipStreamSynchronize(c->stream));
+    rc = wait_export(c, done);
+    if (rc != NB_OK) return rc;
     rc = status_from_tail(c, with_status);
     if (rc != NB_OK) return rc;
     std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));

@@ -136,7 +136,13 @@ hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each
 hipError_t launch_import(uint32_t count, const float *pos_xyz, const float *vel_xyz, float4 *pos_rec, float4 *vel_rec, hipStream_t s);
+// done.word != NULL (outputs in mapped host memory): the launch's last workgroup writes done.seq there once all outputs are home
+struct ExportDone {
+    uint32_t *counter = nullptr;  // a zeroed device word (left zero)
+    uint32_t *word = nullptr;     // the device's address of the host word to write
+    uint32_t seq = 0;
+};
 hipError_t launch_export(uint32_t count, const float4 *pos_rec, const float4 *vel_rec, float4 *inst, float *pos_xyz, float *vel_xyz,
-                         const uint32_t *status_src, uint32_t *status_dst, hipStream_t s, uint32_t device_libm = 0);
+                         const uint32_t *status_src, uint32_t *status_dst, hipStream_t s, uint32_t device_libm = 0, ExportDone done = ExportDone{});
 
 }  // namespace nbk

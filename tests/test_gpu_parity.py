@@ -1126,6 +1126,50 @@ def test_update_instance_nbody_called_every_frame(nb, oracle):
     assert_bits_equal(positions, p_ref)
 
 
+@pytest.mark.parametrize("n", [1, 100, 255, 256, 257, 1000, 2048, 2049])
+def test_small_set_dropin_waits_on_the_word_the_export_kernel_writes(nb, oracle, monkeypatch, n):
+    """Up to 2 048 bodies the drop-in calls (and Scene's download) do not wait on the stream: the export kernel's LAST workgroup writes
+    a sequence number behind the results in the mapped host buffer once every workgroup's stores are home, and the host polls that
+    word (nb_api.hip: wait_export; ~4 us per call, tools/ubench_sync.hip).  Held here: the results are the stream-wait path's bits
+    (NB_DROPIN_POLL=0) frame after frame -- sets of one workgroup and of several, one past the line -- for both controllers and
+    Scene.step, and a long run of calls (the word's sequence, the counter left at zero, the periodic stream wait) stays exact."""
+    pos, vel = state3d(oracle, n, seed=900 + n)
+    frames = 6
+    got = {}
+    for poll in ("0", "1"):
+        monkeypatch.setenv("NB_DROPIN_POLL", poll)
+        positions, velocities = pos.copy(), vel.copy()
+        old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+        inst = np.zeros((n, 4, 4), np.float32)
+        for _ in range(frames):
+            nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+        pb, vb, instb = positions.copy(), velocities.copy(), np.zeros((n, 4, 4), np.float32)
+        for _ in range(2):
+            nb.update_instance_boids(instb, pb, old_p, vb, old_v)
+        with nb.Scene(pos, vel) as sc:
+            for _ in range(3):
+                sc.step()          # one step + download of positions, velocities and matrices
+            ps, vs, ins = sc.positions().copy(), sc.velocities().copy(), sc.instances().copy()
+        got[poll] = (positions, velocities, inst.copy(), pb, vb, instb, ps, vs, ins)
+        nb.update_release()
+    for a, b in zip(got["0"], got["1"]):
+        assert_bits_equal(a, b)
+    p_ref, v_ref = oracle.run(pos, vel, frames)
+    assert_bits_equal(got["1"][0], p_ref)
+    assert_bits_equal(got["1"][1], v_ref)
+    if n == 100:   # the reference's default entity_count: 2 500 consecutive frames against the oracle's
+        monkeypatch.setenv("NB_DROPIN_POLL", "1")
+        positions, velocities = pos.copy(), vel.copy()
+        old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+        inst = np.zeros((n, 4, 4), np.float32)
+        for _ in range(2500):
+            nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+        p_ref, v_ref, inst_ref = oracle.run(pos, vel, 2500, want_instances=True)
+        assert_bits_equal(positions, p_ref)
+        assert_bits_equal(velocities, v_ref)
+        assert matrices_equal(inst, inst_ref)
+
+
 def test_scene_step_refreshes_host_mirrors(nb, oracle):
     pos, vel = state3d(oracle, 100, seed=53)
     with nb.Scene.from_state(pos, vel) as sc:

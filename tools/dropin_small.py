@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-call time of the drop-in functions on small sets with the pinned buffer staged by DMA copies (NB_DROPIN_ZERO_COPY=0)
-against the pack / unpack kernels touching it through the bus themselves (=1): where kZeroCopyMax belongs."""
+against the pack / unpack kernels touching it through the bus themselves (=1): where kZeroCopyMax belongs; and (round 4) with the
+host waiting on the stream (NB_DROPIN_POLL=0) against polling the word the export kernel writes behind its results (the default
+up to 2 048 bodies)."""
 import os
 import sys
 import time
@@ -24,8 +26,9 @@ def per_call(fn, reps):
 for n in [int(x) for x in sys.argv[1:]] or [100, 256, 512, 1024, 2048, 4096, 8192, 16384]:
     pos, vel = nb.init_state(n, 1234)
     row = []
-    for knob in ("0", "1"):
+    for knob, poll in (("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["NB_DROPIN_ZERO_COPY"] = knob
+        os.environ["NB_DROPIN_POLL"] = poll
         nb.reload_env()
         inst = np.zeros((n, 4, 4), np.float32)
         p, v = pos.copy(), vel.copy()
@@ -35,6 +38,7 @@ for n in [int(x) for x in sys.argv[1:]] or [100, 256, 512, 1024, 2048, 4096, 819
         g_boids = per_call(lambda: nb.update_instance_boids(inst, p, op, v, ov), 400)
         with nb.Scene(pos, vel) as sc:
             g_scene = per_call(sc.step, 400)   # one step + download of positions, velocities and matrices
-        row.append(f"zero_copy={knob}: n-body {g_nbody * 1e6:7.1f} us boids {g_boids * 1e6:7.1f} us Scene.step {g_scene * 1e6:7.1f} us")
+        row.append(f"zero_copy={knob} poll={poll}: n-body {g_nbody * 1e6:7.1f} us boids {g_boids * 1e6:7.1f} us Scene.step {g_scene * 1e6:7.1f} us")
     print(f"N={n:6d}  " + "  |  ".join(row), flush=True)
 os.environ.pop("NB_DROPIN_ZERO_COPY", None)
+os.environ.pop("NB_DROPIN_POLL", None)
