@@ -1,6 +1,5 @@
 """bench.py's roofline arithmetic, on the CPU: every printed fraction must mean what it says.  The kernel
 times fed in are the ones measured in profiles/r03 and profiles/r04."""
-import os
 import sys
 
 import pytest

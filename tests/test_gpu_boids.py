@@ -1,7 +1,5 @@
 """GPU parity tests of the boids controller (update_instance_boids, src/main.rs:443-526):
 the HIP kernel through the C ABI against the CPU oracle, bit for bit."""
-import ctypes
-import os
 
 import numpy as np
 import pytest

@@ -1,7 +1,6 @@
 """Randomised differential tests on the GPU: many small random problems (sizes, shard ranges, constants, data scales,
 launch shapes) -- STRICT n-body and boids against the oracle bit for bit, FAST against a tolerance.  Seeded, so a failure
 is reproducible from the printed case."""
-import ctypes
 import os
 
 import numpy as np

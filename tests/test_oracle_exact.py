@@ -4,7 +4,6 @@ flag, no numpy in the loop.  What this pins: that the C oracle (gcc -O2 -ffp-con
 really compute "every operation rounded once, in the reference's order" -- no contraction into FMAs, no excess precision, no
 reassociation -- including subnormal results and the coincident / self pair (0 * G / bias = 0).  What it cannot pin is the Rust
 original itself (the reference cannot be built here: DESIGN.md section 2, "parity unpinned")."""
-import struct
 from fractions import Fraction
 
 import numpy as np
