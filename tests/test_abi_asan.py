@@ -20,9 +20,7 @@ ASAN_LIB = os.path.join(ROOT, "nenbody_amd", "lib", "libnenbody_hip_asan.so")
 def _hipcc():
     return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
 
-
 def test_host_abi_under_address_and_ub_sanitizers():
-    import ctypes
 
     import nenbody_amd
 
