@@ -164,7 +164,7 @@ def test_fast_pairs_form_on_shards_random_problems(nb, oracle, monkeypatch, case
 
     rng = np.random.default_rng(9000 + case)
     np_ = int(rng.choice([2, 4]))
-    world = int(rng.choice([2, 3, 4, 5, 8]))
+    world = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 16]))
     nb_per_rank = int(rng.integers(1, 7 if np_ == 4 else 10))
     n = 128 * np_ * nb_per_rank * world
     monkeypatch.setenv("NB_RING", "1")
