@@ -384,6 +384,24 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["fast_pairs_on_shards"] = {"error": repr(e)}
 
+        if world > 1 and not args.no_ring:
+            # which of the two FAST forms the MACHINE prefers: ShardedScene.choose_form times both on the state in hand (the slowest
+            # rank's time counts) -- the answer a host gets when it asks instead of trusting the library's one-GPU line
+            leg["name"] = "fast_form_chosen_by_timing"
+            try:
+                sc = nb.ShardedScene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST))
+                if sc.partners:
+                    preheat(sc.step, torch, dist, world, sc.device, args.preheat_ms)
+                    chosen = sc.choose_form(steps=10, warm=3)
+                    line["fast_form_chosen_by_timing"] = {"chosen": chosen, "partners": sc.partners,
+                                                          "ms_per_step": {k_: 1e3 * v_ for k_, v_ in sc.form_times.items()},
+                                                          "what": "ShardedScene.choose_form(steps=10): the pairs form (two exchanges per step) "
+                                                                  "against the ordered fold (one), wall time of the slowest rank"}
+                sc.sync()
+                del sc
+            except Exception as e:  # pragma: no cover
+                line["fast_form_chosen_by_timing"] = {"error": repr(e)}
+
         # what a leg costs WITHOUT the preheat: five timed steps right behind the idle gap of a fresh scene (the clock ramp included)
         leg["name"] = "unpreheated"
         try:

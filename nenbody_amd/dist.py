@@ -12,6 +12,7 @@ torch is plumbing here: device buffers, the stream, the collective.  The step it
 from __future__ import annotations
 
 import ctypes
+import time
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -321,6 +322,56 @@ class ShardedScene:
     def step_n(self, k: int) -> None:
         for _ in range(int(k)):
             self.step()
+
+    def choose_form(self, steps: int = 4, warm: int = 2) -> str:
+        """FAST where the pairs form is planned: time ``steps`` steps each way -- the pairs form with its two exchanges, the ordered
+        fold with its one -- on the current state, every rank taking the SLOWEST rank's time (one all-reduce), keep the faster form
+        for the steps to come, and put the state back.  What the second exchange costs between real GPUs is not known ahead of
+        time (the library's own line is drawn from one-GPU timings and a one-rank communicator); this asks
+        the machine.  Collective: every rank calls it, every rank gets the same answer -- "pairs" or "ordered"
+        (``form_times``: the two times in seconds per step).  Other shapes return "ordered" at once."""
+        torch = self.torch
+        self.form_times = None
+        if not self.partners:
+            return "ordered"
+        self._wait_pending()
+        saved = (self.pos[0].clone(), self.pos[1].clone(), self.vel.clone(), self.cur, self.steps_done, self.velfull_valid)
+        pairs = (self.partners, self.scratch)
+        sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
+        ordered = (0, torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None)
+
+        def fence():
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self.dist.barrier(group=self.group)
+
+        def restore():
+            self.pos[0].copy_(saved[0])
+            self.pos[1].copy_(saved[1])
+            self.vel.copy_(saved[2])
+            self.cur, self.steps_done, self.velfull_valid = saved[3], saved[4], saved[5]
+
+        times = []
+        for partners, scratch in (pairs, ordered):
+            self.partners, self.scratch = partners, scratch
+            self.step_n(warm)
+            fence()
+            t0 = time.perf_counter()
+            self.step_n(steps)
+            fence()
+            times.append((time.perf_counter() - t0) / max(1, steps))
+            restore()
+        on_device = self.dist.get_backend(self.group) == "nccl"
+        t = torch.tensor(times, dtype=torch.float64, device=self.device if on_device else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        t_pairs, t_ordered = (float(x) for x in t.tolist())
+        self.form_times = {"pairs": t_pairs, "ordered": t_ordered}
+        if t_pairs <= t_ordered:
+            self.partners, self.scratch = pairs
+            return "pairs"
+        self.partners, self.scratch = ordered
+        self.sums = self.recv = None
+        return "ordered"
 
     def sync(self) -> None:
         """Wait for the queued steps; raises NbError (NB_ERR_STATE) if a kernel reported a failure (``nb_launch_status``)."""

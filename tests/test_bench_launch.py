@@ -51,6 +51,8 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     pairs = line["fast_pairs_on_shards"]
     assert pairs["partners"] == 1 and pairs["roofline"]["kernel"] == "step_fast_ring_kernel" and pairs["value"] > 0
     assert 0 < pairs["roofline"]["frac"] < 1 and pairs["roofline"]["frac_nominal"] > pairs["roofline"]["frac"]
+    chosen = line["fast_form_chosen_by_timing"]
+    assert chosen["chosen"] in ("pairs", "ordered") and set(chosen["ms_per_step"]) == {"pairs", "ordered"}
     assert set(line["unpreheated"]) >= {"strict", "fast"}
     assert line["boids_controller"]["split_form"]["value"] > 0
 

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=False):
+def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=False, slow=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,7 +36,27 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=F
         params = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST) if (overlap or ring) else None
         sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap, ring=True if ring else False)
         assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap
-        if ring:   # two exchanges per step: the halves that belong to the ranks in front (point to point), then the positions
+        if ring and slow:   # choose_form: both forms timed on the state in hand, the slower rank's time decides, the state is put back
+            import time as _time
+
+            sc.step()
+            before = (sc.positions().copy(), sc.velocities().copy(), sc.cur, sc.steps_done)
+            name = "ring_fold" if slow == "pairs" else "step"
+            real = getattr(sc.backend, name)
+
+            def slowed(*a, **kw):
+                if rank == world - 1:   # one slow rank is enough: every rank takes the slowest rank's time
+                    _time.sleep(0.05)
+                return real(*a, **kw)
+
+            setattr(sc.backend, name, slowed)
+            chosen = sc.choose_form(steps=2, warm=1)
+            setattr(sc.backend, name, real)
+            assert chosen == ("ordered" if slow == "pairs" else "pairs"), (chosen, sc.form_times)
+            assert sc.partners == (0 if chosen == "ordered" else ring) and set(sc.form_times) == {"pairs", "ordered"}
+            assert (sc.positions() == before[0]).all() and (sc.velocities() == before[1]).all() and (sc.cur, sc.steps_done) == before[2:]
+            sc.step_n(k - 1)
+        elif ring:   # two exchanges per step: the halves that belong to the ranks in front (point to point), then the positions
             assert sc.partners == ring and not sc.overlap
             sent, gathers = [], []
             real_batch, real_gather = dist.batch_isend_irecv, dist.all_gather_into_tensor
@@ -174,3 +194,17 @@ def test_ring_needs_equal_ranks(oracle):
         nenbody_amd.ShardedScene(pos, vel, fast, backend=OracleBackend(), device="cpu", rank=1, world=3, ring=True)
     sc = nenbody_amd.ShardedScene(pos[:48], vel[:48], backend=OracleBackend(), device="cpu", rank=1, world=3)   # STRICT
     assert sc.partners == 0
+
+
+@pytest.mark.parametrize("world,n,k,partners,slow", [(2, 64, 3, 1, "pairs"), (3, 48, 3, 2, "ordered")])
+def test_choose_form_times_both_forms_and_every_rank_agrees(tmp_path, oracle, world, n, k, partners, slow):
+    """ShardedScene.choose_form: where the pairs form is planned, both forms are timed on the current state (the slowest rank's
+    time counts), the faster one is kept and the state is put back -- here one form is slowed down on ONE rank, so every rank must
+    pick the other; stepping on gives the unsharded result either way."""
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), False, False, partners, slow), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
