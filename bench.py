@@ -102,6 +102,8 @@ def committed_traffic(nb, kernels, n, count):
         return None, f"the built library's device code could not be hashed ({e.__class__.__name__}: {e}): traffic not reported"
     if t.get("code_sha") != running:
         return None, "profiles/hbm_traffic.json was measured on other device code (code_sha differs from the built library's): stale, not reported"
+    if t.get("n") == n and t.get("count") != count and str(count) in t.get("shards", {}):   # one rank's share of a multi-GPU job
+        t = dict(t["shards"][str(count)], code_sha=running)
     if t.get("n") != n or t.get("count") != count:
         return None, "profiles/hbm_traffic.json is for another shape"
     missing = [k for k in kernels if k not in t.get("kernels", {})]

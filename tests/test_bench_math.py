@@ -54,3 +54,30 @@ def test_three_d_data_has_its_own_operation_counts():
 def test_a_zero_kernel_time_does_not_divide():
     r = bench.roofline_fractions("strict", "planar", "step_strict_sl_kernel", N, N, 0.0)
     assert r["frac"] == r["frac_nominal"] == r["frac_executed"] == 0.0
+
+
+def test_committed_traffic_knows_the_shapes_of_a_multi_gpu_job(tmp_path, monkeypatch):
+    """profiles/hbm_traffic.json holds the one-GPU shape and, under "shards", one rank's share at 2 / 4 / 8 ranks; a stamp for other
+    device code, an unknown shape or a missing kernel give None and the reason, never a wrong number"""
+    import json
+    import types
+
+    import bench
+
+    (tmp_path / "profiles").mkdir()
+    doc = {"n": 131072, "count": 131072, "code_sha": "abc", "source": "profiles/rNN/pmc/",
+           "kernels": {"step_strict_sl_kernel": {"bytes_per_launch": 25}, "planes_kernel": {"bytes_per_launch": 4}},
+           "shards": {"16384": {"n": 131072, "count": 16384, "source": "profiles/rNN/pmc_shard/c16384/",
+                                "kernels": {"step_strict_bc_kernel": {"bytes_per_launch": 7}, "planes_kernel": {"bytes_per_launch": 4},
+                                            "step_fast_ring_kernel": {"bytes_per_launch": 24}}}}}
+    (tmp_path / "profiles" / "hbm_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    nb = types.SimpleNamespace(_lib=types.SimpleNamespace(kernel_code_sha=lambda: "abc"))
+    assert bench.committed_traffic(nb, ["step_strict_sl_kernel", "planes_kernel"], 131072, 131072)[0] == 29
+    got, why = bench.committed_traffic(nb, ["step_strict_bc_kernel", "planes_kernel"], 131072, 16384)
+    assert got == 11 and "pmc_shard/c16384" in why
+    assert bench.committed_traffic(nb, ["step_fast_ring_kernel", "planes_kernel"], 131072, 16384)[0] == 28
+    assert bench.committed_traffic(nb, ["step_strict_bc_kernel", "planes_kernel"], 131072, 32768)[0] is None      # no such shape
+    assert bench.committed_traffic(nb, ["ring_reduce_kernel"], 131072, 16384)[0] is None                          # kernel not measured
+    stale = types.SimpleNamespace(_lib=types.SimpleNamespace(kernel_code_sha=lambda: "other"))
+    assert bench.committed_traffic(stale, ["step_strict_bc_kernel", "planes_kernel"], 131072, 16384)[0] is None   # other device code

@@ -35,3 +35,15 @@ for f in smoke.log pytest_gpu.log; do
 done
 python tools/pmc_summary.py "$DST/pmc" --json profiles/hbm_traffic.json --n 131072 --count 131072 --source "$DST/pmc/" > "$DST/pmc_summary.txt"
 tail -n 12 "$DST/pmc_summary.txt"
+# one rank's share at 2 / 4 / 8 ranks (STRICT, FAST ordered, the pairs form on shards): HBM counters only, added to the same file
+for cdir in "$SRC"/pmc_shard/c*; do
+    [ -d "$cdir" ] || continue
+    C=$(basename "$cdir"); C=${C#c}
+    mkdir -p "$DST/pmc_shard/c$C"
+    for d in "$cdir"/*_p[0-9]*; do
+        [ -d "$d" ] || continue
+        f=$(find "$d" -name "*_counter_collection.csv" | head -1)
+        [ -n "$f" ] && cp "$f" "$DST/pmc_shard/c$C/$(basename "$d").counter_collection.csv"
+    done
+    python tools/pmc_summary.py "$DST/pmc_shard/c$C" --json profiles/hbm_traffic.json --n 131072 --count "$C" --shard --source "$DST/pmc_shard/c$C/" > "$DST/pmc_shard/c${C}_summary.txt"
+done

@@ -23,7 +23,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(root, json_path=None, n=None, count=None, source=None):
+def main(root, json_path=None, n=None, count=None, source=None, shard=False):
     agg = collections.defaultdict(list)
     dur = collections.defaultdict(list)
     for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
@@ -54,7 +54,17 @@ def main(root, json_path=None, n=None, count=None, source=None):
             wc = vals["SQ_WAVE_CYCLES"]
             print(f"   -> wave time: issuing {vals['SQ_ACTIVE_INST_ANY'] / wc:.1%}, issue-stalled "
                   f"{vals.get('SQ_WAIT_INST_ANY', 0) / wc:.1%}, parked (s_waitcnt/barrier) {vals.get('SQ_WAIT_ANY', 0) / wc:.1%}")
-    if json_path:
+    if json_path and shard:
+        # one rank's share of a multi-GPU job (count of n bodies): added to the existing file under "shards", same stamp required
+        from nenbody_amd._lib import kernel_code_sha
+
+        out = json.load(open(json_path))
+        if out.get("code_sha") != kernel_code_sha():
+            raise SystemExit(f"{json_path} is stamped for other device code: write the one-GPU shape first")
+        out.setdefault("shards", {})[str(count)] = {"n": n, "count": count, "source": source or root, "kernels": traffic}
+        json.dump(out, open(json_path, "w"), indent=1)
+        print(f"added shard {count} to {json_path}: {sorted(traffic)}", file=sys.stderr)
+    elif json_path:
         from nenbody_amd._lib import kernel_code_sha, kernel_source_sha
 
         out = {"_comment": "HBM-side bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE x 1024 x 2 [gfx950 correction for wide "
@@ -73,5 +83,6 @@ if __name__ == "__main__":
     ap.add_argument("--n", type=int, default=131072)
     ap.add_argument("--count", type=int, default=131072)
     ap.add_argument("--source")
+    ap.add_argument("--shard", action="store_true", help="add the kernels as the shape of one rank's share (--count of --n bodies) to an existing --json file")
     a = ap.parse_args()
-    main(a.root, a.json, a.n, a.count, a.source)
+    main(a.root, a.json, a.n, a.count, a.source, a.shard)

@@ -42,6 +42,23 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
     rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_ring/ring_p$i" -- python3 "$ROOT/tools/ring_times.py" 131072 8 > "$OUT/pmc_ring_p$i.log" 2>&1
     echo "pmc ring pass $i ($set) rc=$?"
 done
+# one rank's share at 2 / 4 / 8 ranks: the two HBM counters of every form a rank may run -- STRICT, FAST as ordered pairs, FAST in
+# the pairs form on shards (tools/shard_run.py, tools/ring_times.py) -- so that a multi-GPU bench line carries `roofline.traffic` too
+for P in 2 4 8; do
+    C=$((131072 / P))
+    i=0
+    for set in "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i + 1))
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_shard/c$C/strict_p$i" -- python3 "$ROOT/tools/shard_run.py" $C 5 > "$OUT/pmc_shard_c${C}_strict_p$i.log" 2>&1
+        echo "pmc shard $C strict pass $i rc=$?"
+        export NB_MODE=fast
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_shard/c$C/fast_p$i" -- python3 "$ROOT/tools/shard_run.py" $C 5 > "$OUT/pmc_shard_c${C}_fast_p$i.log" 2>&1
+        echo "pmc shard $C fast pass $i rc=$?"
+        unset NB_MODE
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$ROOT/$OUT/pmc_shard/c$C/ring_p$i" -- python3 "$ROOT/tools/ring_times.py" 131072 $P > "$OUT/pmc_shard_c${C}_ring_p$i.log" 2>&1
+        echo "pmc shard $C ring pass $i rc=$?"
+    done
+done
 # the smoke of the same sources on the same box, beside the profiles (collect_profiles.sh copies it: no stale smoke.log)
 python3 -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
 echo "smoke rc=$?"
