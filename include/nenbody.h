@@ -170,6 +170,9 @@ uint64_t nb_steps_done(const nb_ctx *ctx);
  * One upload, one step, one download per call.  The device contexts live inside the library between calls: up to three,
  * keyed by controller, body count and constants (a host may alternate controllers or entity counts from frame to frame; only
  * a fourth shape rebuilds one); calls are serialised by an internal lock.
+ * The call returns when the results are in the caller's arrays.  Up to 2 048 bodies (the reference's ceiling, main.rs:653) the
+ * calling thread SPINS on a word the last kernel writes behind the results (4 us sooner than a stream wait; at most 2 ms, then it
+ * falls back to the stream wait); larger sets block in hipStreamSynchronize.
  * params == NULL -> the reference constants. */
 int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
                              float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz, size_t n_velocities,
