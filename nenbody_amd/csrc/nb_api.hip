@@ -50,7 +50,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy, dropin_poll;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy, dropin_poll, dropin_poll_budget_us;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -110,6 +110,7 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->boids_slices = read_knob("NB_BOIDS_SLICES");
     d->dropin_zero_copy = read_knob("NB_DROPIN_ZERO_COPY");
     d->dropin_poll = read_knob("NB_DROPIN_POLL");
+    d->dropin_poll_budget_us = read_knob("NB_DROPIN_POLL_BUDGET_US");
     d->selftest_control = read_knob("NB_SELFTEST_CONTROL");
     return d;
 }
@@ -753,7 +754,8 @@ int make_boids_args(const nb_boids_params &p, uint32_t n_total, uint32_t first, 
 // the chip two waves per SIMD (512 workgroups of four waves), whole tiles per slice.  NB_BOIDS_SLICES names the count (tests, tools/).
 void boids_split_shape(uint32_t n_total, uint32_t count, uint32_t tile, uint32_t *slices, uint32_t *j_chunk)
 {
-    const uint32_t ntiles = (n_total + tile - 1u) / tile, groups = (count + 255u) / 256u;
+    // (an empty rank -- count == 0 -- launches nothing; it still gets a shape, so that a host can size scratch for every rank alike)
+    const uint32_t ntiles = (n_total + tile - 1u) / tile, groups = std::max(1u, (count + 255u) / 256u);
     uint32_t sl = overrides().boids_slices.or_else((512u + groups - 1u) / groups);
     if (sl < 1u) sl = 1u;
     if (sl > ntiles) sl = ntiles;
@@ -833,6 +835,7 @@ struct nb_ctx {
     float *hxfer_dev = nullptr;  // the device's address of hxfer (mapped host memory: kernels of the small-set drop-in read and write it directly)
     uint32_t *done_counter = nullptr;  // export_kernel's workgroup counter (ExportDone)
     uint32_t done_seq = 0, polled_calls = 0;
+    uint32_t poll_holdoff = 0, poll_backoff = 0;  // calls that take the stream wait after a poll that timed out (wait_export)
     void *scratch = nullptr;
     StatusWord status;        // sticky failure word of this context's block-chain launches
     int cur = 0;
@@ -969,6 +972,10 @@ static int ensure_xfer(nb_ctx *c)
 static nbk::ExportDone export_done(nb_ctx *c, bool polled)
 {
     nbk::ExportDone d;
+    if (polled && c->poll_holdoff) {  // the word kept the host spinning not long ago (wait_export): the stream wait for a while
+        --c->poll_holdoff;
+        polled = false;
+    }
     if (polled) {
         d.counter = c->done_counter;
         d.word = (uint32_t *)(c->hxfer_dev + 22 * (size_t)c->n + kDoneWordAt);
@@ -977,23 +984,45 @@ static nbk::ExportDone export_done(nb_ctx *c, bool polled)
     return d;
 }
 
-// waits for the export launched last: the polled word, or the stream
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// waits for the export launched last: the polled word, or the stream.  The poll is ADAPTIVE: a word that does not arrive within
+// kPollBudget (the GPU is busy with something else -- the reference renders through the same device every frame, so the export
+// kernel may routinely queue behind graphics work) costs that call the spin AND the stream wait, so the next 64 calls of the
+// context go straight to the stream wait, twice as many after every further timeout (up to 4 096); a poll that succeeds
+// resets the back-off.  The fallback also re-zeroes the workgroup counter: only the LAST workgroup of an export launch resets it,
+// so a launch that died half way would leave every later polled call waiting for a count that never comes.
 static int wait_export(nb_ctx *c, const nbk::ExportDone &d)
 {
     if (d.word) {
         const volatile uint32_t *const w = (const volatile uint32_t *)(c->hxfer + 22 * (size_t)c->n + kDoneWordAt);
-        constexpr auto kPollBudget = std::chrono::milliseconds(2);
+        const auto kPollBudget = std::chrono::microseconds(overrides().dropin_poll_budget_us.or_else(2000u));  // (the knob: tests)
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spins = 1;; ++spins) {
             if (*w == d.seq) {
                 std::atomic_thread_fence(std::memory_order_acquire);
+                c->poll_backoff = 0;
                 // (now and then the runtime gets to see the stream idle: it retires its own bookkeeping at a wait)
                 if ((++c->polled_calls & 1023u) == 0u) NB_HIP(c, hipStreamSynchronize(c->stream));
                 return NB_OK;
             }
             if ((spins & 255u) == 0u && std::chrono::steady_clock::now() - t0 > kPollBudget) break;
-            __builtin_ia32_pause();
+            cpu_relax();
         }
+        c->poll_backoff = c->poll_backoff ? std::min(c->poll_backoff * 2u, 4096u) : 64u;
+        c->poll_holdoff = c->poll_backoff;
+        NB_HIP(c, hipStreamSynchronize(c->stream));
+        if (*w != d.seq) NB_HIP(c, hipMemsetAsync(c->done_counter, 0, sizeof(uint32_t), c->stream));  // (stream-ordered in front of the next export)
+        return NB_OK;
     }
     NB_HIP(c, hipStreamSynchronize(c->stream));
     return NB_OK;
@@ -2613,7 +2642,8 @@ NB_EXPORT size_t nb_boids_split_scratch_bytes(const nb_boids_params *params, uin
     nbk::BoidsArgs a;
     uint32_t tile = 0, slices = 0, chunk = 0;
     std::string err;
-    if (make_boids_args(p, n_total, 0, count ? count : 1u, &a, &tile, &err) != NB_OK) return 0;
+    if (count == 0u) return 0;  // a rank without bodies launches nothing
+    if (make_boids_args(p, n_total, 0, count, &a, &tile, &err) != NB_OK) return 0;
     boids_split_shape(n_total, count, tile, &slices, &chunk);
     return boids_split_bytes(n_total, count, slices);
 }

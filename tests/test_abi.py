@@ -181,6 +181,20 @@ def test_boids_defaults_and_launch_validation(nb):
     assert lib.nb_launch_random_step(0, 0, a, b, 1, 0, None) == _lib.NB_ERR_INVALID
 
 
+def test_boids_split_scratch_for_a_rank_without_bodies(nb):
+    """sizing the split form's scratch for an empty rank (count == 0, as every other shard call accepts) divided by
+    zero and killed the host with SIGFPE.  It needs no scratch: 0; a rank with bodies gets rows for every slice."""
+    import ctypes
+
+    lib = nb.load()
+    bp = nb._lib.default_boids_params()
+    assert lib.nb_boids_split_scratch_bytes(ctypes.byref(bp), 131072, 0) == 0
+    assert lib.nb_boids_split_scratch_bytes(None, 1000, 0) == 0
+    some = lib.nb_boids_split_scratch_bytes(ctypes.byref(bp), 131072, 16384)
+    assert some >= 16384 * 3 * 16      # at least one slice of rows
+    assert lib.nb_boids_split_scratch_bytes(ctypes.byref(bp), 131072, 1) > 0
+
+
 def test_shard_argument_contract_and_no_device(nb):
     """nb_shard_*: arguments are validated before any device work; without a GPU nothing can be created."""
     from nenbody_amd import _lib

