@@ -249,6 +249,29 @@ int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uint32_t firs
 int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *pos_out,
                           void *vel, const void *sums, const void *recv, void *stream);
 
+/* The same step in PHASES, so that its exchanges can hide behind compute (round 5; SURVEY.md section 8e "Overlap";
+ * src/main.rs:415, 425-432: every pair reads the start-of-step snapshot only).  A rank's pairs fall into those whose two bodies
+ * it owns itself -- they need nothing from another GPU -- and those with the bodies of the D ranks in front:
+ *   NB_RING_OWN    pairs inside the rank's own slot, as many as one round of workgroups holds (3 068 of the 4 224 own-slot
+ *                  sub-tiles of an 8-rank share of 131 072 bodies: 23 us on an MI355X).  Reads ONLY records
+ *                  [first, first + count) of pos_in -- which the rank's own nb_launch_ring_finish wrote -- so it may run while
+ *                  the all-gather of the other slots of pos_in is still landing.
+ *   NB_RING_REST   every other pair (the whole snapshot must be in place), and the sums of the halves that belong to the ranks
+ *                  in front: records [count, (D + 1) count) of `sums` are final when it completes -- the second exchange can start.
+ *   NB_RING_SUMS   the rank's own sums, records [0, count) of `sums`: it can run beside the second exchange.
+ *   then nb_launch_ring_finish as above.
+ * One step, with `x` a second stream for the exchanges:
+ *     OWN | wait(all-gather of the last step) | REST | [x: second exchange] SUMS | wait(x) | finish | [x: all-gather]
+ * Same arguments in every call of a step (same scratch, untouched between them: nb_ring_scratch_bytes() covers both forms).
+ * The sums are added in another (fixed) order than nb_launch_ring_fold's: run-to-run identical, FAST's tolerances, its own bits.
+ * nb_ring_phased: 1 where the shape can run its step this way (nb_ring_partners() > 0 and the rank's rows fit one launch -- every
+ * rank count of BASELINE's config 4; config 5's ranks walk their rows in groups and keep nb_launch_ring_fold: two exchanges of
+ * 2 MB per peer against 13.6 ms of compute), 0 where it keeps nb_launch_ring_fold; or a negative nb_status. */
+enum { NB_RING_OWN = 1, NB_RING_REST = 2, NB_RING_SUMS = 3 };
+int nb_ring_phased(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
+int nb_launch_ring_fold_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
+                              void *sums, void *scratch, size_t scratch_bytes, void *stream);
+
 /* One boids step (main.rs:443-526) for bodies [first, first+count) of a set of n_total:
  *   pos_in, vel_in    n_total records each: the snapshots old_positions / old_velocities (main.rs:459-460), read only
  *   pos_out, vel_out  n_total records each; only [first, first+count) is written (a multi-GPU caller all-gathers BOTH)
@@ -327,12 +350,17 @@ int nb_shard_pairs_partners(const nb_shard *sh);
  * and counts, sums reassociated) -- what lets eight ranks run the controller about eight times as fast as one instead of 3.4
  * times; off (the default): bit-identical to the reference whatever the world size. */
 int nb_shard_set_boids_split(nb_shard *sh, int on);
-/* FAST only ("Overlap"): with `on` != 0 every step folds this rank's own slot of the snapshot while the
- * exchange of the other slots is still in flight on a second stream, waits for it, then folds the rest (the two phases of
- * nb_launch_step_phase).  The order of the additions changes, which FAST may and STRICT may not: a STRICT shard (and a world
- * of one) ignores the request and stays kernel -> exchange in sequence.  A host-supplied exchange (nb_shard_use_gather)
- * receives the second stream and must order its work on it. */
+/* FAST only ("Overlap"): with `on` != 0 the exchanges of a step run on a second stream, behind compute that
+ * does not need them.  A shard in the ordered fold folds its own slot of the snapshot while the all-gather of the other slots is
+ * still in flight, waits for it, then folds the rest (the two phases of nb_launch_step_phase).  A shard in the pairs form
+ * (nb_shard_pairs_partners() > 0, nb_ring_phased()) runs the phases of nb_launch_ring_fold_phase: pairs inside its own slot while
+ * the all-gather lands, every other pair, then the second exchange beside the reduce of its own sums (round 5).  The order of the
+ * additions changes, which FAST may and STRICT may not: a STRICT shard (and a world of one) ignores the request and stays
+ * kernel -> exchange in sequence.  Host-supplied exchanges (nb_shard_use_gather / nb_shard_use_ring) receive the second stream
+ * and must order their work on it. */
 int nb_shard_set_overlap(nb_shard *sh, int on);
+/* 1 where a step of this shard takes the pairs form in phases with both exchanges on the second stream, else 0. */
+int nb_shard_pairs_overlapped(const nb_shard *sh);
 /* This rank's index range. */
 int nb_shard_range(const nb_shard *sh, uint32_t *first, uint32_t *count);
 /* Host -> device: ALL n positions and ALL n velocities (identical on every rank; the rank keeps its own velocities). */

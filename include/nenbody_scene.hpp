@@ -148,6 +148,7 @@ public:
     uint32_t first() const { return first_; }
     uint32_t count() const { return count_; }
     int pairs_partners() const { return nb_shard_pairs_partners(sh_); }  // D of the pairs form a step will take; 0: the ordered fold
+    bool pairs_overlapped() const { return nb_shard_pairs_overlapped(sh_) == 1; }  // the pairs form in phases, both exchanges on the second stream (set_overlap)
     void step(uint32_t k = 1) { check_sh(nb_shard_step(sh_, k)); }
     void step_boids(uint32_t k = 1, const nb_boids_params *params = nullptr) { check_sh(nb_shard_step_boids(sh_, k, params)); }
     // FAST only (a STRICT shard ignores it): fold the rank's own slot while the exchange of the others is in flight

@@ -28,6 +28,8 @@ NB_MODE_STRICT = 0
 NB_MODE_FAST = 1
 NB_PHASE_RANGE = 0
 NB_PHASE_REST = 1
+# phases of the pairs form on shards (nb_launch_ring_fold_phase)
+NB_RING_OWN, NB_RING_REST, NB_RING_SUMS = 1, 2, 3
 
 _STATUS_NAMES = {
     NB_ERR_INVALID: "NB_ERR_INVALID",
@@ -117,6 +119,8 @@ PROTOTYPES = {
     "nb_ring_partners": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32]),
     "nb_ring_scratch_bytes": (c_size_t, [POINTER(NbParams), c_uint32, c_uint32, c_uint32]),
     "nb_launch_ring_fold": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nb_ring_phased": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32]),
+    "nb_launch_ring_fold_phase": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nb_launch_ring_finish": (
         c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_status": (c_int, [c_void_p]),
@@ -132,6 +136,7 @@ PROTOTYPES = {
     "nb_shard_use_ring": (c_int, [c_void_p, RING_FN, c_void_p]),
     "nb_shard_set_pairs": (c_int, [c_void_p, c_int]),
     "nb_shard_pairs_partners": (c_int, [c_void_p]),
+    "nb_shard_pairs_overlapped": (c_int, [c_void_p]),
     "nb_shard_set_boids_split": (c_int, [c_void_p, c_int]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
     "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),

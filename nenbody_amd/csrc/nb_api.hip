@@ -50,7 +50,7 @@ struct Knob {
 };
 struct DebugOverrides {
     Knob tile, fast_pairs_w, fast_pairs_np, fast_pairs_chunk, fast_ib, fast_groups, fast_waves, fast_slices, fast_no_share, strict_force_ieee, force_3d, strict_no_packed, strict_lanes, strict_unroll,
-        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy, dropin_poll, dropin_poll_budget_us;
+        strict_pc, strict_bc, strict_sl, fast_sl, fast_pairs, ring, ring_np, ring_ga, ring_wpb, ring_c4_own, ring_c4_rest, ring_cap, inst_device_libm, boids_slices, bc_spin_budget, bc_prio, boids_pc, boids_tile, boids_force, selftest_control, roctx, dropin_zero_copy, dropin_poll, dropin_poll_budget_us;
     uint32_t generation = 0;  // bumped by every reload: invalidates cached plans
 };
 
@@ -102,6 +102,9 @@ const DebugOverrides *parse_overrides(uint32_t generation)
     d->ring_np = read_knob("NB_RING_NP");
     d->ring_ga = read_knob("NB_RING_GA");
     d->ring_wpb = read_knob("NB_RING_WPB");
+    d->ring_c4_own = read_knob("NB_RING_C4_OWN");
+    d->ring_c4_rest = read_knob("NB_RING_C4_REST");
+    d->ring_cap = read_knob("NB_RING_CAP");
     d->bc_spin_budget = read_knob("NB_BC_SPIN_BUDGET");
     d->bc_prio = read_knob("NB_BC_PRIO");
     d->boids_pc = read_knob("NB_BOIDS_PC");
@@ -2355,6 +2358,8 @@ struct RingPlan {
     uint32_t np;    // packed pairs of bodies per lane: 4 (blocks of 512) where the shard is whole blocks of 512, else 2 (256)
     uint32_t ga, wpb;
     uint32_t partners;  // 0: this shape does not take the form
+    uint32_t c4_own, c4_rest, cap;  // the step in phases: sub-tiles per workgroup, sub-tiles of a block's own part in the first phase (0: the kernels' defaults)
+    bool phased;        // the shape can run its step in phases (nb_launch_ring_fold_phase)
 };
 // Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and enough pairs per rank that what
 // the form saves pays for its second exchange: against the ordered fold of the same shard it saves n_total x count / 3e7 us
@@ -2372,14 +2377,19 @@ int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_
     if (dbg.ring_np.set && (dbg.ring_np.v == 2u || dbg.ring_np.v == 4u)) out->np = dbg.ring_np.v;
     out->ga = dbg.ring_ga.or_else(0u);
     out->wpb = dbg.ring_wpb.or_else(0u) & ~3u;
+    out->c4_own = dbg.ring_c4_own.or_else(0u);
+    out->c4_rest = dbg.ring_c4_rest.or_else(0u);
+    out->cap = dbg.ring_cap.or_else(0u);
+    out->phased = false;
     if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
     if (!dbg.ring.or_else((uint64_t)n_total * count >= kRingMinPairs ? 1u : 0u)) return NB_OK;
     out->partners = nbk::ring_partners(n_total, first, count, out->np);
+    out->phased = out->partners != 0u && nbk::ring_phased(n_total, first, count, out->np, out->ga, out->wpb);
     return NB_OK;
 }
 size_t ring_scratch_bytes(const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count)
 {
-    return nbk::strict_bc_scratch_bytes(n_total) + nbk::ring_scratch_floats(n_total, first, count, rp.np, rp.ga, rp.wpb) * sizeof(float);
+    return nbk::strict_bc_scratch_bytes(n_total) + nbk::ring_scratch_floats(n_total, first, count, rp.np, rp.ga, rp.wpb, rp.c4_own, rp.c4_rest, rp.cap) * sizeof(float);
 }
 int cached_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, const RingPlan **out, std::string *err)
 {
@@ -2439,6 +2449,17 @@ int launch_ring_fold_planned(const nb_params &p, const RingPlan &rp, uint32_t n_
     hipError_t e = nbk::launch_fast_ring(a, rp.np, rp.ga, rp.wpb, scratch, (float4 *)sums, stream);
     if (e != hipSuccess) {
         *err = std::string("nb: kernel launch failed (ring fold): ") + hipGetErrorString(e);
+        return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+int launch_ring_phase_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
+                              void *sums, void *scratch, hipStream_t stream, std::string *err)
+{
+    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, nullptr, nullptr);
+    hipError_t e = nbk::launch_fast_ring_phase(a, rp.np, rp.ga, rp.wpb, rp.c4_own, rp.c4_rest, rp.cap, (uint32_t)phase, scratch, (float4 *)sums, stream);
+    if (e != hipSuccess) {
+        *err = std::string("nb: kernel launch failed (ring fold, phase ") + std::to_string(phase) + "): " + hipGetErrorString(e);
         return NB_ERR_HIP;
     }
     return NB_OK;
@@ -2512,6 +2533,55 @@ NB_EXPORT int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uin
         if (rc != NB_OK) return rc;
     }
     return launch_ring_fold_planned(p, *rp, n_total, first, count, pos_in, sums, scratch, (hipStream_t)stream, &g_tls_error);
+}
+
+NB_EXPORT int nb_ring_phased(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    const RingPlan *rp = nullptr;
+    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    return rp->phased ? 1 : 0;
+}
+
+NB_EXPORT int nb_launch_ring_fold_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
+                                        void *sums, void *scratch, size_t scratch_bytes, void *stream)
+{
+    nb_params p;
+    if (params)
+        p = *params;
+    else
+        nb_default_params(&p);
+    if (!pos_in || !sums || !scratch) {
+        g_tls_error = "nb_launch_ring_fold_phase: pos_in, sums and scratch must be non-null";
+        return NB_ERR_INVALID;
+    }
+    if (phase < NB_RING_OWN || phase > NB_RING_SUMS) {
+        g_tls_error = "nb_launch_ring_fold_phase: phase must be NB_RING_OWN, NB_RING_REST or NB_RING_SUMS";
+        return NB_ERR_INVALID;
+    }
+    const RingPlan *rp = nullptr;
+    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (!rp->phased) {
+        g_tls_error = "nb_launch_ring_fold_phase: this shape does not run its step in phases (nb_ring_phased() == 0): use nb_launch_ring_fold";
+        return NB_ERR_UNSUPPORTED;
+    }
+    if (scratch_bytes < ring_scratch_bytes(*rp, n_total, first, count)) {
+        g_tls_error = "nb_launch_ring_fold_phase: scratch smaller than nb_ring_scratch_bytes()";
+        return NB_ERR_INVALID;
+    }
+    rc = check_device(&g_tls_error);
+    if (rc != NB_OK) return rc;
+    if (!stream) {
+        rc = select_device_of(pos_in, &g_tls_error);
+        if (rc != NB_OK) return rc;
+    }
+    return launch_ring_phase_planned(p, *rp, n_total, first, count, phase, pos_in, sums, scratch, (hipStream_t)stream, &g_tls_error);
 }
 
 NB_EXPORT int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,

@@ -105,7 +105,17 @@ uint32_t fast_pairs_chunk(uint32_t n_total, uint32_t chunk);  // the chunk a lau
 // ga: a-blocks per launch (0: default), wpb: waves per a-block (0: default).  scratch = planes area + ring_scratch_floats() floats.
 // Shapes: count divides n_total (>= 2 ranks), first a multiple of count, count a multiple of 128 np.
 uint32_t ring_partners(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np);  // 0: the shape cannot take the form
-size_t ring_scratch_floats(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb);
+size_t ring_scratch_floats(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own = 0, uint32_t c4_rest = 0,
+                           uint32_t cap = 0);
+// the step in PHASES (round 5): can this shape run them (one launch covers the rank)?  what: 1 the pairs inside the rank's own slot
+// that one round of workgroups holds, 2 every other pair + the sums of the ranks in front, 3 the rank's own sums; c4_*: sub-tiles
+// per workgroup of a phase, cap: sub-tiles of a block's own part that phase 1 takes (0: defaults)
+bool ring_phased(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb);
+hipError_t launch_fast_ring_phase(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap, uint32_t what,
+                                  void *scratch, float4 *sums, hipStream_t s);
+hipError_t launch_ring_phase_kernels(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap, uint32_t what,
+                                     const uint32_t *flags, const float *px, const float *py, const float *pz, float *scratch, float4 *sums,
+                                     hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
 hipError_t launch_fast_ring(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, void *scratch, float4 *sums, hipStream_t s);
 hipError_t launch_fast_ring_kernels(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, const uint32_t *flags, uint32_t generation,
                                     const float *px, const float *py, const float *pz, float *scratch, float4 *sums, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)

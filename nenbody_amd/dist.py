@@ -91,6 +91,23 @@ class HipBackend:
             check(self.lib.nb_launch_ring_fold(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), sums.data_ptr(),
                                                scratch.data_ptr(), scratch.numel(), stream))
 
+    def ring_phased(self, params: NbParams, n_total: int, first: int, count: int) -> bool:
+        """can this shape run its step in phases (``nb_launch_ring_fold_phase``: both exchanges behind compute)?"""
+        r = int(self.lib.nb_ring_phased(ctypes.byref(params), n_total, first, count))
+        if r < 0:
+            check(r)
+        return r == 1
+
+    def ring_fold_phase(self, params, n_total, first, count, phase, pos_in, sums, scratch) -> None:
+        """one phase of the fold: NB_RING_OWN reads only the rank's own slot of pos_in, NB_RING_REST the whole snapshot (and leaves
+        the sums of the ranks in front final), NB_RING_SUMS makes the rank's own sums"""
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        with torch.cuda.device(pos_in.device):
+            check(self.lib.nb_launch_ring_fold_phase(ctypes.byref(params), n_total, first, count, int(phase), pos_in.data_ptr(),
+                                                     sums.data_ptr(), scratch.data_ptr(), scratch.numel(), stream))
+
     def ring_finish(self, params, n_total, first, count, pos_in, pos_out, vel, sums, recv) -> None:
         import torch
 
@@ -136,7 +153,7 @@ class ShardedScene:
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, device=None, group=None,
                  backend=None, rank: Optional[int] = None, world: Optional[int] = None, overlap: bool = False,
-                 ring: Optional[bool] = None):
+                 ring: Optional[bool] = None, ring_overlap: Optional[bool] = None):
         import torch
         import torch.distributed as dist
 
@@ -188,6 +205,14 @@ class ShardedScene:
             self.recv = torch.zeros((self.partners * self.count, 4), dtype=torch.float32, device=self.device)
         self.overlap = bool(overlap) and self.params.mode == _lib.NB_MODE_FAST and world > 1 and not self.partners
         self._pending = None     # the exchange in flight (overlap): a torch.distributed work handle, or None
+        # The pairs form with its exchanges hidden (round 5; nb_launch_ring_fold_phase): a round's worth of the pairs inside the
+        # rank's own slot of step k + 1 runs while step k's all-gather lands; the second exchange leaves as soon as the sums of the
+        # ranks in front are final, and the rank's own sums are made beside it.  ring_overlap=None: overlap decides (True: where the
+        # shape allows); True: required; False: fold, exchange, finish, all-gather in sequence.
+        can = bool(self.partners) and hasattr(self.backend, "ring_phased") and self.backend.ring_phased(self.params, self.n, self.first, self.count)
+        if ring_overlap and not can:
+            raise ValueError("ring_overlap=True: this shape does not run its step in phases (nb_ring_phased() == 0)")
+        self.ring_overlap = can and bool(overlap if ring_overlap is None else ring_overlap)
         if self.partners:
             sb = self.backend.ring_scratch_bytes(self.params, self.n, self.first, self.count)
         elif self.overlap:
@@ -219,7 +244,10 @@ class ShardedScene:
         return None  # these paths complete before returning
 
     # -- the pairs form's second exchange: chunk d of `sums` goes to rank + d, chunk d - 1 of `recv` comes from rank - d --------
-    def _ring_exchange(self) -> None:
+    def _ring_exchange_start(self):
+        """issues the exchange; returns what ``_ring_exchange_wait`` needs.  RCCL: the sends and receives run on the
+        communicator's stream behind what the current stream holds NOW (the sums of the ranks in front), so launches that
+        follow on the current stream overlap with them; the other paths complete before returning."""
         dist, S = self.dist, self.count
         on_host = dist.get_backend(self.group) != "nccl" and self.sums.device.type != "cpu"
         sums = self.sums.cpu() if on_host else self.sums   # rehearsal path (gloo with device buffers): stage through the host
@@ -231,10 +259,17 @@ class ShardedScene:
                 to, frm = dist.get_global_rank(self.group, to), dist.get_global_rank(self.group, frm)
             ops.append(dist.P2POp(dist.isend, sums[d * S:(d + 1) * S], to, self.group, tag=d))
             ops.append(dist.P2POp(dist.irecv, recv[(d - 1) * S:d * S], frm, self.group, tag=d))
-        for req in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops), (recv if on_host else None)
+
+    def _ring_exchange_wait(self, started) -> None:
+        reqs, staged = started
+        for req in reqs:
             req.wait()   # RCCL: the current stream waits, not the host
-        if on_host:
-            self.recv.copy_(recv)
+        if staged is not None:
+            self.recv.copy_(staged)
+
+    def _ring_exchange(self) -> None:
+        self._ring_exchange_wait(self._ring_exchange_start())
 
     def _wait_pending(self) -> None:
         """overlap: make the current stream wait for the exchange in flight (no host wait with RCCL)"""
@@ -294,7 +329,19 @@ class ShardedScene:
     # -- one step: local update, then the exchange ------------------------------------------------------
     def step(self) -> None:
         src, dst = self.pos[self.cur], self.pos[self.cur ^ 1]
-        if self.partners:
+        if self.partners and self.ring_overlap:
+            # src's other slots may still be landing; this rank's own slot of src was written by its own last finish
+            be, a = self.backend, (self.params, self.n, self.first, self.count)
+            be.ring_fold_phase(*a, _lib.NB_RING_OWN, src, self.sums, self.scratch)
+            self._wait_pending()
+            be.ring_fold_phase(*a, _lib.NB_RING_REST, src, self.sums, self.scratch)     # the sums of the ranks in front are final
+            started = self._ring_exchange_start()
+            be.ring_fold_phase(*a, _lib.NB_RING_SUMS, src, self.sums, self.scratch)     # ... the rank's own beside the exchange
+            self._ring_exchange_wait(started)
+            be.ring_finish(*a, src, dst, self.vel, self.sums, self.recv)
+            self._pending = self._all_gather_slots(dst, async_op=True)
+        elif self.partners:
+            self._wait_pending()
             self.backend.ring_fold(self.params, self.n, self.first, self.count, src, self.sums, self.scratch)
             self._ring_exchange()
             self.backend.ring_finish(self.params, self.n, self.first, self.count, src, dst, self.vel, self.sums, self.recv)
@@ -311,6 +358,7 @@ class ShardedScene:
                                         self.scratch)
             self._pending = self._all_gather_slots(dst, async_op=True)
         else:
+            self._wait_pending()
             if self.count:
                 self.backend.step(self.params, self.n, self.first, self.count, src, dst, self.vel, self.scratch)
             if self.world > 1:
@@ -324,36 +372,43 @@ class ShardedScene:
             self.step()
 
     def choose_form(self, steps: int = 4, warm: int = 2) -> str:
-        """FAST where the pairs form is planned: time ``steps`` steps each way -- the pairs form with its two exchanges, the ordered
-        fold with its one -- on the current state, every rank taking the SLOWEST rank's time (one all-reduce), keep the faster form
-        for the steps to come, and put the state back.  What the second exchange costs between real GPUs is not known ahead of
-        time (the library's own line is drawn from one-GPU timings and a one-rank communicator); this asks
-        the machine.  Collective: every rank calls it, every rank gets the same answer -- "pairs" or "ordered"
-        (``form_times``: the two times in seconds per step).  Other shapes return "ordered" at once."""
+        """FAST where the pairs form is planned: time ``steps`` steps of every form this shape can take -- the pairs form with its
+        two exchanges in sequence ("pairs"), the same with the exchanges behind compute ("pairs_overlapped", where
+        ``nb_ring_phased``), the ordered fold with its one exchange ("ordered") -- on the current state, every rank taking the
+        SLOWEST rank's time (one all-reduce), keep the fastest for the steps to come, and put the state back.  What an exchange
+        costs between real GPUs is not known ahead of time (the library's own line is drawn from one-GPU
+        timings and a one-rank communicator); this asks the machine.  Collective: every rank calls it, every rank gets the same
+        answer (``form_times``: seconds per step of each candidate).  Other shapes return "ordered" at once."""
         torch = self.torch
         self.form_times = None
         if not self.partners:
             return "ordered"
         self._wait_pending()
         saved = (self.pos[0].clone(), self.pos[1].clone(), self.vel.clone(), self.cur, self.steps_done, self.velfull_valid)
-        pairs = (self.partners, self.scratch)
         sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
-        ordered = (0, torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None)
+        phased = hasattr(self.backend, "ring_phased") and self.backend.ring_phased(self.params, self.n, self.first, self.count)
+        # candidate -> (partners, scratch, ring_overlap)
+        cands = {"pairs": (self.partners, self.scratch, False)}
+        if phased:
+            cands["pairs_overlapped"] = (self.partners, self.scratch, True)
+        cands["ordered"] = (0, torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None, False)
 
         def fence():
+            self._wait_pending()
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
             self.dist.barrier(group=self.group)
 
         def restore():
+            self._wait_pending()
             self.pos[0].copy_(saved[0])
             self.pos[1].copy_(saved[1])
             self.vel.copy_(saved[2])
             self.cur, self.steps_done, self.velfull_valid = saved[3], saved[4], saved[5]
 
-        times = []
-        for partners, scratch in (pairs, ordered):
-            self.partners, self.scratch = partners, scratch
+        names, times = list(cands), []
+        for name in names:
+            self.partners, self.scratch, self.ring_overlap = cands[name]
             self.step_n(warm)
             fence()
             t0 = time.perf_counter()
@@ -364,14 +419,12 @@ class ShardedScene:
         on_device = self.dist.get_backend(self.group) == "nccl"
         t = torch.tensor(times, dtype=torch.float64, device=self.device if on_device else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        t_pairs, t_ordered = (float(x) for x in t.tolist())
-        self.form_times = {"pairs": t_pairs, "ordered": t_ordered}
-        if t_pairs <= t_ordered:
-            self.partners, self.scratch = pairs
-            return "pairs"
-        self.partners, self.scratch = ordered
-        self.sums = self.recv = None
-        return "ordered"
+        self.form_times = dict(zip(names, (float(x) for x in t.tolist())))
+        best = min(names, key=lambda k: (self.form_times[k], names.index(k)))   # (a tie keeps the earlier, simpler form)
+        self.partners, self.scratch, self.ring_overlap = cands[best]
+        if best == "ordered":
+            self.sums = self.recv = None
+        return best
 
     def sync(self) -> None:
         """Wait for the queued steps; raises NbError (NB_ERR_STATE) if a kernel reported a failure (``nb_launch_status``)."""
@@ -502,6 +555,11 @@ class NativeShard:
     def partners(self) -> int:
         """D of the pairs form a step will take (``nb_shard_pairs_partners``); 0: the ordered fold and its one exchange."""
         return int(self._lib.nb_shard_pairs_partners(self._sh))
+
+    @property
+    def pairs_overlapped(self) -> bool:
+        """does a step take the pairs form in phases, both exchanges on a second stream (``nb_shard_pairs_overlapped``)?"""
+        return int(self._lib.nb_shard_pairs_overlapped(self._sh)) == 1
 
     def upload(self, positions, velocities) -> None:
         """Replaces the state (all n positions, all n velocities; the rank keeps its own range of the latter)."""

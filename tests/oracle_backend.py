@@ -63,7 +63,52 @@ class OracleBackend:
         return -(-(count + hmax) // count) - 1
 
     def ring_scratch_bytes(self, params, n_total, first, count):
-        return 16
+        return 2 * count * 16    # the phases keep two rows of count records here between their calls
+
+    # the step in PHASES (nb_launch_ring_fold_phase): 1 = pairs inside the rank's own slot (here: those of the first 70 % of its
+    # bodies -- a part, as the library's one round of workgroups is), 2 = every other pair + the sums of the ranks in front, 3 = the
+    # rank's own sums.  Phase 1 sees a snapshot whose OTHER slots are NaN: a read of a record that may still be in flight poisons
+    # the result.
+    def ring_phased(self, params, n_total, first, count):
+        return self.ring_partners(params, n_total, first, count) > 0
+
+    def ring_fold_phase(self, params, n_total, first, count, phase, pos_in, sums, scratch):
+        keep = scratch.view(torch.float32).reshape(2 * count, 4)
+        own_acc, rest_acc = keep[:count, :3].numpy(), keep[count:, :3].numpy()
+        if phase == 3:
+            sums[:count, :3] = torch.from_numpy(own_acc + rest_acc)
+            sums[:count, 3] = 0
+            return
+        old = pos_in[:n_total, :3].contiguous().numpy().copy()
+        head = (7 * count + 9) // 10     # bodies whose own-slot pairs phase 1 takes
+        if phase == 1:
+            mask = np.ones(n_total, bool)
+            mask[first:first + count] = False
+            old[mask] = np.nan
+            own_acc[:] = 0
+        else:
+            rest_acc[:] = 0
+        out = np.zeros((sums.shape[0], 3), np.float32)
+        for l in range(count):
+            i = first + l
+            k = np.arange(self._fwd(i, n_total))
+            in_head = (l + 1 + k < count) & (l < head)      # the other body is one of this rank's own, and the pair is phase 1's
+            k = k[in_head] if phase == 1 else k[~in_head]
+            if not len(k):
+                continue
+            js = (i + 1 + k) % n_total
+            d = old[js] - old[i]
+            t = d / ((d * d).sum(axis=1, dtype=np.float32) + np.float32(params.bias))[:, None]
+            if phase == 1:
+                own_acc[l] += t.sum(axis=0, dtype=np.float32)
+                np.subtract.at(own_acc, l + 1 + k, t)
+            else:
+                rest_acc[l] += t.sum(axis=0, dtype=np.float32)
+                np.subtract.at(out, l + 1 + k, t)
+        if phase == 2:
+            rest_acc[:] += out[:count]            # (own-slot pairs phase 1 left: their other halves stay in the rank)
+            sums[count:, :3] = torch.from_numpy(out[count:])
+            sums[count:, 3] = 0
 
     def ring_fold(self, params, n_total, first, count, pos_in, sums, scratch):
         old = pos_in[:n_total, :3].contiguous().numpy()

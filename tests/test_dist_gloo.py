@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=False, slow=None):
+def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=False, slow=None, ring_overlap=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,47 +34,71 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=F
         pos, vel = oracle.init_state(n, seed=4321)
         pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
         params = nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST) if (overlap or ring) else None
-        sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap, ring=True if ring else False)
-        assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap
+        sc = nenbody_amd.ShardedScene(pos, vel, params, backend=OracleBackend(), device="cpu", overlap=overlap, ring=True if ring else False,
+                                      ring_overlap=ring_overlap)
+        assert (sc.first, sc.count) == nenbody_amd.partition(n, world)[rank] and sc.overlap == overlap and sc.ring_overlap == bool(ring_overlap)
         if ring and slow:   # choose_form: both forms timed on the state in hand, the slower rank's time decides, the state is put back
             import time as _time
 
             sc.step()
             before = (sc.positions().copy(), sc.velocities().copy(), sc.cur, sc.steps_done)
-            name = "ring_fold" if slow == "pairs" else "step"
-            real = getattr(sc.backend, name)
+            names = ("ring_fold", "ring_fold_phase") if slow == "pairs" else ("step",)
+            reals = {name: getattr(sc.backend, name) for name in names}
 
-            def slowed(*a, **kw):
-                if rank == world - 1:   # one slow rank is enough: every rank takes the slowest rank's time
-                    _time.sleep(0.05)
-                return real(*a, **kw)
+            def slowed(real):
+                def call(*a, **kw):
+                    if rank == world - 1:   # one slow rank is enough: every rank takes the slowest rank's time
+                        _time.sleep(0.05)
+                    return real(*a, **kw)
+                return call
 
-            setattr(sc.backend, name, slowed)
+            for name in names:
+                setattr(sc.backend, name, slowed(reals[name]))
             chosen = sc.choose_form(steps=2, warm=1)
-            setattr(sc.backend, name, real)
-            assert chosen == ("ordered" if slow == "pairs" else "pairs"), (chosen, sc.form_times)
-            assert sc.partners == (0 if chosen == "ordered" else ring) and set(sc.form_times) == {"pairs", "ordered"}
+            for name in names:
+                setattr(sc.backend, name, reals[name])
+            # three candidates: the pairs form with its exchanges in sequence / behind compute, and the ordered fold
+            assert set(sc.form_times) == {"pairs", "pairs_overlapped", "ordered"}
+            assert (chosen == "ordered") if slow == "pairs" else chosen.startswith("pairs"), (chosen, sc.form_times)
+            assert sc.partners == (0 if chosen == "ordered" else ring)
+            assert sc.ring_overlap == (chosen == "pairs_overlapped")
             assert (sc.positions() == before[0]).all() and (sc.velocities() == before[1]).all() and (sc.cur, sc.steps_done) == before[2:]
             sc.step_n(k - 1)
         elif ring:   # two exchanges per step: the halves that belong to the ranks in front (point to point), then the positions
             assert sc.partners == ring and not sc.overlap
-            sent, gathers = [], []
+            sent, gathers, order = [], [], []
             real_batch, real_gather = dist.batch_isend_irecv, dist.all_gather_into_tensor
 
             def counting_batch(ops):
                 sent.append(sorted((op.op.__name__, op.peer, op.tensor.numel()) for op in ops))
+                order.append("exchange")
                 return real_batch(ops)
 
             def counting_gather(out, inp, *a, **kw):
                 gathers.append(out.numel())
+                order.append("gather")
                 return real_gather(out, inp, *a, **kw)
 
+            def logged(name, real):   # the launches between the collectives, in the order they are issued
+                def call(*a, **kw):
+                    order.append(name if name != "ring_fold_phase" else f"phase{a[4]}")
+                    return real(*a, **kw)
+                return call
+
+            for name in ("ring_fold", "ring_fold_phase", "ring_finish"):
+                setattr(sc.backend, name, logged(name, getattr(sc.backend, name)))
             dist.batch_isend_irecv, dist.all_gather_into_tensor = counting_batch, counting_gather
             sc.step_n(k)
             dist.batch_isend_irecv, dist.all_gather_into_tensor = real_batch, real_gather
             want = sorted([("isend", (rank + d) % world, sc.count * 4) for d in range(1, ring + 1)] +
                           [("irecv", (rank - d) % world, sc.count * 4) for d in range(1, ring + 1)])
             assert sent == [want] * k and gathers == [world * sc.slot * 4] * k, (sent, gathers)
+            # one step: pairs that need no other GPU first (phase 1), every other pair (2), the second exchange as soon as the sums of
+            # the ranks in front exist, the rank's own sums (3) beside it, the finish, the all-gather -- which the NEXT step's first
+            # phase does not wait for
+            per_step = (["phase1", "phase2", "exchange", "phase3", "ring_finish", "gather"] if ring_overlap
+                        else ["ring_fold", "exchange", "ring_finish", "gather"])
+            assert order == per_step * k, order
         elif boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
             gathers = []
             real = dist.all_gather_into_tensor
@@ -163,6 +187,24 @@ def test_sharded_fast_with_overlapped_exchange(tmp_path, oracle, world, n, k):
 
     sc = nenbody_amd.ShardedScene(pos, vel, backend=OracleBackend(), device="cpu", overlap=True)   # STRICT, world 1
     assert not sc.overlap
+
+
+@pytest.mark.parametrize("world,n,k,partners", [(2, 64, 4, 1), (3, 48, 3, 2), (4, 64, 3, 2), (8, 64, 2, 4)])
+def test_sharded_fast_pairs_with_the_exchanges_behind_compute(tmp_path, oracle, world, n, k, partners, ring_overlap=True):
+    """ring_overlap (FAST, equal ranks; nb_launch_ring_fold_phase): pairs inside a rank's own slot need no other GPU, so a round's
+    worth of them runs while the last step's all-gather is still landing; the second exchange leaves as soon as the sums of the
+    ranks in front are final and the rank's own sums are made beside it.  The worker checks the order of launches and collectives
+    of every step and the peers and sizes of every message; the test double computes the first phase from a snapshot whose other
+    slots are NaN (a record read before it could have arrived poisons the run); here: every rank's replica matches the unsharded
+    run to FAST's tolerance, on worlds of 2, 3, 4 and 8."""
+    mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path), False, False, partners, None, ring_overlap), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.isfinite(got["pos"]).all() and np.isfinite(got["vel"]).all()
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
 
 
 @pytest.mark.parametrize("world,n,k,partners", [(2, 64, 4, 1), (3, 48, 3, 2), (3, 51, 3, 2), (4, 64, 3, 2), (8, 64, 2, 4), (5, 55, 2, 3)])

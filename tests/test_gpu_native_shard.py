@@ -203,11 +203,11 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
         pos, vel = state3d(oracle, n, seed=n) if seed is None else oracle.init_state(n, seed)
         with nenbody_amd.NativeShard(pos, vel, nenbody_amd.default_params(mode=mode), rank=rank, world=world,
                                      gather=gather, overlap=overlap, ring=ring if with_ring else None) as sh:
-            partners = sh.partners
+            partners, overlapped = sh.partners, sh.pairs_overlapped
             drive(sh, schedule or SCHEDULE)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sh.positions(), vel=sh.local_velocities(),
                      inst=sh.local_instances(), first=sh.first, count=sh.count, calls=len(calls), ring_calls=len(ring_calls),
-                     partners=partners)
+                     partners=partners, overlapped=overlapped)
     finally:
         dist.destroy_process_group()
 
@@ -273,8 +273,9 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
     schedule = (("nbody", 2), ("nbody", 1))
     import torch.multiprocessing as mp
 
-    # (the last arm: the pairs form with nb_shard_set_overlap requested as well -- the ring comes first, and the scratch the
-    # overlapped phases would need must not replace the larger one the ring needs)
+    # (the last arm: the pairs form with nb_shard_set_overlap -- round 5: the step in phases, both exchanges handed the second
+    # stream, pairs inside the rank's own slot while the all-gather lands; and the scratch the ordered fold's phases would need must
+    # not replace the larger one the ring needs)
     for with_ring, overlap in ((True, False), (False, False), (True, True)):
         out = tmp_path / (("ring" if with_ring else "ordered") + ("-overlap" if overlap else ""))
         out.mkdir()
@@ -289,6 +290,7 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
             first, count = int(got["first"]), int(got["count"])
             assert (first, count) == nb.partition(n, world)[r]
             assert int(got["partners"]) == (partners if with_ring else 0)
+            assert bool(got["overlapped"]) == (with_ring and overlap)
             assert int(got["calls"]) == 3 and int(got["ring_calls"]) == (3 if with_ring else 0)
             # three steps of tens of thousands of bodies: a few pairs come within the softening length, where any rounding
             # difference is amplified -- the bulk at FAST's per-step tolerance, the worst body bounded
@@ -347,13 +349,14 @@ def test_rccl_leg_of_the_pairs_form_on_a_one_rank_communicator(nb, oracle):
     assert np.abs(p[:16384] - pos[:16384]).max() > 0
 
 
-@pytest.mark.parametrize("mode_name", ["strict", "fast"])
+@pytest.mark.parametrize("mode_name", ["strict", "fast", "fast_overlapped"])
 def test_eight_ranks_as_threads_of_one_process(nb, oracle, monkeypatch, mode_name):
     """EIGHT ranks -- the world of BASELINE.json's configs 4 and 5 -- as eight threads of this process, each with its own native
     shard and stream on the one GPU ("one process (or thread) per GPU"), both exchanges supplied by the
     host through a barrier: nb_shard_step's indexing at the world size the 8-GPU node will run (D = 4 partners of the pairs form,
     the antipodal rank among them), and the library's per-thread plan caches under eight concurrent callers.  STRICT: every
-    rank's bits equal the oracle's; FAST: the pairs form, two exchanges per step, within FAST's tolerance."""
+    rank's bits equal the oracle's; FAST: the pairs form, two exchanges per step, within FAST's tolerance; fast_overlapped: the same
+    step in phases (nb_shard_set_overlap), both exchanges on the shards' second streams."""
     import threading
 
     world, n, steps = 8, 32768, 2
@@ -395,8 +398,9 @@ def test_eight_ranks_as_threads_of_one_process(nb, oracle, monkeypatch, mode_nam
 
         try:
             with nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=rank, world=world, gather=gather,
-                                ring=ring if mode == nb.NB_MODE_FAST else None) as sh:
+                                ring=ring if mode == nb.NB_MODE_FAST else None, overlap=mode_name == "fast_overlapped") as sh:
                 partners = sh.partners
+                assert sh.pairs_overlapped == (mode_name == "fast_overlapped")
                 sh.step(steps)
                 sh.sync()
                 results[rank] = (sh.first, sh.count, partners, sh.positions(), sh.local_velocities(), sh.local_instances())

@@ -14,9 +14,12 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def ring_steps_on_one_gpu(nb, pos, vel, world, params, steps=1, keep=None):
+def ring_steps_on_one_gpu(nb, pos, vel, world, params, steps=1, keep=None, phases=False):
     """`steps` steps of an n-body set cut into `world` equal ranks, every rank's fold and finish on the one GPU, the second
-    exchange and the all-gather by hand.  Returns (positions, velocities).  keep: a dict that receives the ranks' `sums`."""
+    exchange and the all-gather by hand.  Returns (positions, velocities).  keep: a dict that receives the ranks' `sums`.
+    phases: False = nb_launch_ring_fold; True = the step in phases (nb_launch_ring_fold_phase) in the order a host with the
+    exchanges hidden issues them -- and the phase that may run while the all-gather is still landing gets a snapshot whose OTHER
+    slots are NaN: reading a record that could still be in flight poisons the step."""
     import torch
 
     from nenbody_amd.dist import HipBackend
@@ -39,9 +42,21 @@ def ring_steps_on_one_gpu(nb, pos, vel, world, params, steps=1, keep=None):
         sums.append(torch.full(((D + 1) * S, 4), float("nan"), device=dev))   # every record must be written by the fold
         recv.append(torch.full((D * S, 4), float("nan"), device=dev))
         scratch.append(torch.empty((be.ring_scratch_bytes(params, n, r * S, S),), dtype=torch.uint8, device=dev))
+    L = nb._lib
     for _ in range(steps):
         for r in range(world):
-            be.ring_fold(params, n, r * S, S, cur, sums[r], scratch[r])
+            if not phases:
+                be.ring_fold(params, n, r * S, S, cur, sums[r], scratch[r])
+                continue
+            assert be.ring_phased(params, n, r * S, S)
+            only_mine = torch.full_like(cur, float("nan"))
+            only_mine[r * S:(r + 1) * S] = cur[r * S:(r + 1) * S]
+            a = (params, n, r * S, S)
+            be.ring_fold_phase(*a, L.NB_RING_OWN, only_mine, sums[r], scratch[r])
+            be.ring_fold_phase(*a, L.NB_RING_REST, cur, sums[r], scratch[r])
+            sent = sums[r][S:].clone()   # the sums of the ranks in front are final behind NB_RING_REST: what a host would send now
+            be.ring_fold_phase(*a, L.NB_RING_SUMS, cur, sums[r], scratch[r])
+            assert (sent.view(torch.int32) == sums[r][S:].view(torch.int32)).all(), "a later phase touched what had been sent"
         for r in range(world):
             for d in range(1, D + 1):
                 recv[r][(d - 1) * S:d * S] = sums[(r - d) % world][d * S:(d + 1) * S]
@@ -111,6 +126,94 @@ def test_ring_shapes_vs_oracle(nb, oracle, monkeypatch, n, world, np_, ga, wpb, 
     assert np.abs(p3 - p_ref3).max() <= 1e-4 and np.abs(v3 - v_ref3).max() <= 1e-5
 
 
+# the step in PHASES (nb_launch_ring_fold_phase): the same decomposition, a round's worth of the pairs inside a rank's own slot apart
+# from all others; every shape of the phases' kernels: blocks of 512 / 256, one block per rank (an own part of one block), odd and
+# even rings, 2 / 3 / 4 / 8 ranks, sub-tiles per workgroup and the first phase's cap named and by default, planar and 3-D data
+@pytest.mark.parametrize("n,world,np_,c4_own,c4_rest,cap", [
+    (2048, 2, 4, 0, 0, 0),
+    (1536, 3, 4, 0, 0, 0),      # an odd ring
+    (4096, 8, 4, 0, 0, 0),      # one block per rank: its own part is the block against itself
+    (4096, 4, 4, 4, 8, 4),      # the first phase takes half a block's inner pairs, the second the other half
+    (3072, 3, 2, 4, 4, 8),      # blocks of 256 (four sub-tiles each)
+    (8192, 2, 4, 8, 12, 24),    # two ranks: the second rank's first block has no pair with a rank in front
+    (12288, 3, 4, 5, 7, 12),    # workgroup sizes that divide nothing (the cap is rounded to whole workgroups)
+    (16384, 4, 4, 0, 0, 1000),  # a cap beyond every own part: all of it in the first phase
+    (16384, 4, 4, 0, 0, 0),
+])
+@pytest.mark.parametrize("three_d", [False, True], ids=["planar", "3d"])
+def test_ring_phases_vs_oracle(nb, oracle, monkeypatch, n, world, np_, c4_own, c4_rest, cap, three_d):
+    monkeypatch.setenv("NB_RING", "1")
+    monkeypatch.setenv("NB_RING_NP", str(np_))
+    for name, v in (("NB_RING_C4_OWN", c4_own), ("NB_RING_C4_REST", c4_rest), ("NB_RING_CAP", cap)):
+        if v:
+            monkeypatch.setenv(name, str(v))
+    pos, vel = state(oracle, n, 300 + n + world, three_d)
+    params = nb.default_params(mode=nb.NB_MODE_FAST)
+    keep = {}
+    p, v = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, keep, phases=True)
+    assert all(np.isfinite(s[:, :3]).all() and (s[:, 3] == 0).all() for s in keep["sums"]), "a record of `sums` was not written (or read a slot in flight)"
+    p_ref, v_ref = oracle.run(pos, vel, 1)
+    fast_close(v, v_ref, vel)
+    assert np.abs(p - p_ref).max() <= np.abs(v - v_ref).max() + float(np.spacing(np.float32(np.abs(p_ref).max())))
+    if not three_d:
+        assert (p[:, 2] == 0).all() and (v[:, 2] == 0).all()
+    # the one-launch form evaluates the same pairs: the two agree to the rounding of the sums' order
+    p1, v1 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1)
+    fast_close(v, v1, vel)
+    # deterministic: a second run gives the same bits
+    p2, v2 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=True)
+    assert (bits(p) == bits(p2)).all() and (bits(v) == bits(v2)).all()
+    # three steps in a row (buffers and flag words reused, the launch generation moves on)
+    p3, v3 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 3, phases=True)
+    p_ref3, v_ref3 = oracle.run(pos, vel, 3)
+    assert np.abs(p3 - p_ref3).max() <= 1e-4 and np.abs(v3 - v_ref3).max() <= 1e-5
+
+
+@pytest.mark.parametrize("cap", [0, 8])
+@pytest.mark.parametrize("where", ["own", "front", "behind"])
+def test_ring_phases_decide_their_arithmetic_from_what_they_read(nb, oracle, monkeypatch, where, cap):
+    """Each phase has flag words of its own: the first phase's pairs are planar (or may share a reciprocal) when the rank's own slot
+    is, whatever the rest of the set holds -- the rest has not arrived when it runs -- and the second phase obeys the whole set,
+    also for the own-slot pairs the first left it (cap 8: most of them).  One rank's slot is made 3-D and gets a coordinate too
+    large for the shared reciprocal; every rank's step must still be the oracle's."""
+    monkeypatch.setenv("NB_RING", "1")
+    if cap:
+        monkeypatch.setenv("NB_RING_CAP", str(cap))
+    n, world = 8192, 4
+    S = n // world
+    pos, vel = state(oracle, n, 77, False)
+    slot = {"own": 0, "front": 1, "behind": 3}[where]          # seen from rank 0
+    rng = np.random.default_rng(5)
+    pos[slot * S:(slot + 1) * S, 2] = rng.uniform(-100, 100, S).astype(np.float32)
+    pos[slot * S + 17, 0] = np.float32(3e8)
+    params = nb.default_params(mode=nb.NB_MODE_FAST)
+    _, v = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=True)
+    _, v_ref = oracle.run(pos, vel, 1)
+    assert np.isfinite(v).all()
+    fast_close(v, v_ref, vel)
+    _, v2 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=True)
+    assert (bits(v) == bits(v2)).all()
+
+
+def test_shapes_that_run_their_step_in_phases(nb, monkeypatch):
+    from nenbody_amd.dist import HipBackend
+
+    be = HipBackend()
+    fast, strict = nb.default_params(mode=nb.NB_MODE_FAST), nb.default_params()
+    for world in (2, 4, 8):   # BASELINE config 4 at every rank count
+        assert be.ring_phased(fast, 131072, 0, 131072 // world) and be.ring_phased(fast, 131072, 131072 - 131072 // world, 131072 // world)
+    assert be.ring_phased(fast, 65536, 0, 16384)
+    assert not be.ring_phased(strict, 131072, 0, 16384)        # STRICT has no pairs form
+    assert not be.ring_phased(fast, 131072, 0, 131072)
+    assert not be.ring_phased(fast, 16384, 0, 2048)            # below the pairs form's own line
+    # config 5: a rank's rows do not fit one launch (2 GB at 8 ranks), the step is walked in groups of a-blocks and stays
+    # fold -> exchange -> finish -> all-gather: two exchanges of 2 MB per peer against 13.6 ms of compute
+    for world in (2, 4, 8):
+        assert be.ring_partners(fast, 1 << 20, 0, (1 << 20) // world) >= 1 and not be.ring_phased(fast, 1 << 20, 0, (1 << 20) // world)
+    monkeypatch.setenv("NB_RING_GA", "8")                       # a-blocks per launch named: groups, no phases
+    assert not be.ring_phased(fast, 131072, 0, 16384)
+
+
 def test_ring_unshared_reciprocal_and_forced_3d(nb, oracle, monkeypatch):
     monkeypatch.setenv("NB_RING", "1")
     n, world = 4096, 4
@@ -171,11 +274,12 @@ def test_shapes_that_keep_the_ordered_fold(nb, monkeypatch):
 
 
 # BASELINE configs 4 and 5 in the pairs form: every rank's launch set at 2, 4 and 8 ranks
-@pytest.mark.parametrize("n,world", [(131072, 2), (131072, 4), (131072, 8), (1 << 20, 2), (1 << 20, 4), (1 << 20, 8)], ids=lambda x: str(x))
-def test_every_rank_of_configs_4_and_5_in_the_pairs_form(nb, oracle, n, world):
+@pytest.mark.parametrize("n,world,phases", [(131072, 2, False), (131072, 4, False), (131072, 8, False), (1 << 20, 2, False), (1 << 20, 4, False),
+                                            (1 << 20, 8, False), (131072, 2, True), (131072, 4, True), (131072, 8, True)], ids=lambda x: str(x))
+def test_every_rank_of_configs_4_and_5_in_the_pairs_form(nb, oracle, n, world, phases):
     pos, vel = nb.init_state(n, 1234)
     params = nb.default_params(mode=nb.NB_MODE_FAST)
-    p, v = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1)
+    p, v = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=phases)
     S = n // world
     # first, last and six inner bodies of every rank against the oracle and against the same sum carried in binary64
     idx = np.unique(np.concatenate([np.concatenate([[r * S, r * S + S - 1], np.linspace(r * S + 1, r * S + S - 2, 6).astype(np.int64)])
@@ -206,7 +310,7 @@ def test_every_rank_of_configs_4_and_5_in_the_pairs_form(nb, oracle, n, world):
     assert np.abs(p - p1).max() <= dv_all.max() + float(np.spacing(np.float32(np.abs(p1).max()))), msg
     # run to run: the same bits
     if n <= 131072:
-        p2, v2 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1)
+        p2, v2 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=phases)
         assert (bits(p) == bits(p2)).all() and (bits(v) == bits(v2)).all()
 
 
@@ -244,3 +348,8 @@ def test_ring_form_is_deterministic_and_finite_through_the_collapse(nb):
     assert (bits(pa) == bits(pb)).all() and (bits(va) == bits(vb)).all()
     assert np.isfinite(pa).all() and np.isfinite(va).all()
     assert (pa[:, 2] == 0).all()
+    # the same in phases (the exchanges behind compute): its own bits, as reproducible, as finite
+    pc, vc = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100, phases=True)
+    pd, vd = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100, phases=True)
+    assert (bits(pc) == bits(pd)).all() and (bits(vc) == bits(vd)).all()
+    assert np.isfinite(pc).all() and np.isfinite(vc).all() and (pc[:, 2] == 0).all()
