@@ -19,8 +19,9 @@ this device's vector ALU was measured to issue in the same process (`measured_is
 oracle (a C restatement of the reference's Rust; kind "port") timed on the host cores this process may really use.
 `targets` says which mode meets which line of BASELINE.json's north_star: no single mode meets both.
 
-Exit code: 0, or 3 when an informational leg (other mode, 3-D data, boids, CPU baseline) hung -- the headline line is
-still printed, with `aux_error` naming the leg.
+Exit code: 0; 3 when an informational leg (other mode, 3-D data, boids, CPU baseline) hung -- the headline line is still printed,
+with `aux_error` naming the leg; 4 when the line's own `parity_check` failed (STRICT: some bit of the final state differs from the
+golden checksums of that step; FAST: one step further from STRICT than its tolerance) -- the line is printed all the same.
 """
 import argparse
 import json
@@ -86,6 +87,50 @@ def roofline_fractions(mode, data, form, n, count, kernel_ms):
             "pair_evaluations_per_launch": evaluations, "executed_per_interaction": ex}
 
 
+def state_checksums(positions, velocities):
+    """XOR and wrapping 32-bit sum of every bit pattern of the (n, 3) float32 positions and of the velocities: what
+    tests/golden/nbody_golden_c3.npz holds for the headline set after each of 1 000 steps of the CPU oracle (make_golden.py --c3).
+    Returns ([xor_p, xor_v], [sum_p, sum_v]) as Python ints.  Pure numpy (tests/test_bench_math.py)."""
+    import numpy as np
+
+    out_x, out_s = [], []
+    for a in (positions, velocities):
+        u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).ravel()
+        out_x.append(int(np.bitwise_xor.reduce(u)) if u.size else 0)
+        out_s.append(int(u.sum(dtype=np.uint64) & 0xFFFFFFFF))
+    return out_x, out_s
+
+
+def parity_against_golden(n, seed, steps_done, positions, velocities, path=None):
+    """The bench line's own proof of parity: after `steps_done` STRICT steps of the headline set (n = 131 072,
+    seed 1234, the reference's constants) every bit of every body must be the CPU oracle's -- compared through the XOR and the wrapping
+    sum of all position and velocity bit patterns against the committed golden checksums of exactly that step.  Returns the
+    `parity_check` object of the JSON line; `bits_equal` is None (with `why`) where no golden step exists for this run."""
+    import numpy as np
+
+    path = path or os.path.join(ROOT, "tests", "golden", "nbody_golden_c3.npz")
+    out = {"k": int(steps_done), "bits_equal": None, "against": "tests/golden/nbody_golden_c3.npz: XOR + wrapping sum of every position and velocity bit "
+                                                                "pattern after step k of the CPU oracle (C restatement of src/main.rs:404-441)"}
+    try:
+        g = np.load(path)
+    except Exception as e:
+        out["why"] = f"no golden file ({e.__class__.__name__})"
+        return out
+    if n != 131072 or int(g["seed"][0]) != seed or f"n{n}_xor" not in g.files:
+        out["why"] = f"the golden checksums are of n = 131072, seed {int(g['seed'][0])}: nothing to compare n = {n}, seed {seed} with"
+        return out
+    steps = g[f"n{n}_steps"]
+    if steps_done < int(steps[0]) or steps_done > int(steps[-1]):
+        out["why"] = f"the golden file holds steps {int(steps[0])}..{int(steps[-1])}; this run made {steps_done}"
+        return out
+    i = int(steps_done - int(steps[0]))
+    x, s = state_checksums(positions, velocities)
+    gx, gs = [int(v) for v in g[f"n{n}_xor"][i]], [int(v) for v in g[f"n{n}_sum"][i]]
+    out["bits_equal"] = bool(x == gx and s == gs)
+    out["checksums"] = {"xor": x, "sum": s, "golden_xor": gx, "golden_sum": gs}
+    return out
+
+
 def committed_traffic(nb, kernels, n, count):
     """HBM bytes per step from the committed rocprofv3 --pmc passes (tools/pmc_summary.py --json), or (None, why).
 
@@ -144,13 +189,17 @@ def preheat(step, torch, dist, world, dev, ms):
     return int(k.item()) + 2
 
 
-def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False, ring=None, preheat_ms=None):
+def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False, ring=None, preheat_ms=None,
+              ring_overlap=None, choose=False, parity=False):
     """ring: None = the library's plan (FAST on equal ranks of a multi-GPU job: every unordered pair once, two exchanges per
-    step), False = the ordered fold with its one exchange."""
+    step), False = the ordered fold with its one exchange.  ring_overlap: the pairs form in phases, its exchanges behind compute.
+    choose: FAST at world > 1 -- let ShardedScene.choose_form time every form this shape can take and keep the fastest (the
+    timed region then runs that form; `form` in the result says which and what each cost).  parity: check the final state (STRICT:
+    every bit against the golden checksums of that step; FAST: one step against STRICT)."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     params = nb.default_params(mode=mode)
-    sc = nb.ShardedScene(pos, vel, params, overlap=overlap, ring=ring)
+    sc = nb.ShardedScene(pos, vel, params, overlap=overlap, ring=ring, ring_overlap=ring_overlap)
     dev = sc.device
 
     def fence():
@@ -159,19 +208,26 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    if world > 1:
-        # untimed: bring the communicator and its channels up even when --warmup 0 (the target buffer is the scratch side)
-        sc._all_gather_slots(sc.pos[sc.cur ^ 1])
-        if sc.partners:
-            sc._ring_exchange()   # the point-to-point channels of the second exchange too
+    # untimed: bring the communicator and its channels up even when --warmup 0, and VERIFY both exchanges on a known pattern before
+    # any step relies on them (a mismatch moves the exchange to its fallback; `exchange_paths` in the line says which path ran)
+    exchange_paths = sc.verify_exchanges() if world > 1 else None
+    form = None
+    if choose and world > 1 and sc.partners:
+        pre0 = preheat(sc.step, torch, dist, world, dev, args.preheat_ms if preheat_ms is None else preheat_ms)
+        chosen = sc.choose_form(steps=10, warm=3)
+        form = {"chosen": chosen, "ms_per_step": {k_: 1e3 * v_ for k_, v_ in sc.form_times.items()}, "preheat_steps": pre0,
+                "what": "ShardedScene.choose_form(steps=10) on this machine, slowest rank's wall time: the pairs form with its two exchanges in "
+                        "sequence / behind compute (nb_launch_ring_fold_phase), the ordered fold with its one exchange; the timed region runs "
+                        "the fastest"}
     pre = preheat(sc.step, torch, dist, world, dev, args.preheat_ms if preheat_ms is None else preheat_ms)
     for _ in range(warmup):
         sc.step()
     # kernel-only timing: events on the stream the kernels are launched on (torch's current stream), around every launch call of
-    # a step (one: nb_launch_step; the pairs form on shards: nb_launch_ring_fold and nb_launch_ring_finish, the exchange between
-    # them outside the events)
-    calls = ("ring_fold", "ring_finish") if sc.partners else ("step",)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * len(calls))]
+    # a step (one: nb_launch_step; the pairs form on shards: nb_launch_ring_fold and nb_launch_ring_finish -- or the three phases --
+    # the exchanges between them outside the events)
+    calls = (("ring_fold_phase", "ring_finish") if sc.ring_overlap else ("ring_fold", "ring_finish")) if sc.partners else ("step",)
+    per_step = (4 if sc.ring_overlap else 2) if sc.partners else 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * per_step)]
     real = {name: getattr(sc.backend, name) for name in calls}
     used = [0]
 
@@ -190,6 +246,7 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     t0 = time.perf_counter()
     for _ in range(steps):
         sc.step()
+    sc._wait_pending()   # (an overlapped form: the last step's all-gather belongs to the timed region)
     fence()
     t1 = time.perf_counter()
     for name in calls:
@@ -198,12 +255,36 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    # (the overlapped form launches its two phases through step_phase: no per-kernel events there, wall time only)
+    # (the overlapped ORDERED form launches its two phases through step_phase: no per-kernel events there, wall time only)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps if sc.count and used[0] == len(ev) else 0.0
-    kernels = (["step_fast_ring_kernel", "planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"] if sc.partners
+    kernels = (["step_fast_ring_kernel", "planes_kernel" if not sc.ring_overlap else "ring_planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"] if sc.partners
                else step_kernels(nb, mode, sc.n, sc.count))
-    return {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
-            "kernels": kernels, "mode": "fast" if mode == nb.NB_MODE_FAST else "strict", "partners": sc.partners, "world": world}
+    out = {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
+           "kernels": kernels, "mode": "fast" if mode == nb.NB_MODE_FAST else "strict", "partners": sc.partners, "world": world,
+           "ring_overlap": bool(sc.ring_overlap), "exchange_paths": exchange_paths, "form": form}
+    if parity:
+        import numpy as np
+
+        if mode == nb.NB_MODE_STRICT:
+            # every step since the upload counts: preheat + warm-up + timed (+ the form choice restores its state)
+            out["parity_check"] = parity_against_golden(sc.n, 1234, sc.steps_done, sc.positions(), sc.velocities())
+        else:
+            # FAST reassociates: one step of this very form against one STRICT step of the same state, on all bodies
+            a = nb.ShardedScene(pos, vel, nb.default_params(mode=nb.NB_MODE_STRICT))
+            b = nb.ShardedScene(pos, vel, params, ring=bool(sc.partners), ring_overlap=bool(sc.ring_overlap)) if sc.partners else nb.ShardedScene(pos, vel, params, ring=False)
+            b.gather_in_place, b.ring_grouped = sc.gather_in_place, sc.ring_grouped
+            a.step()
+            b.step()
+            pa, pb, va, vb = a.positions(), b.positions(), a.velocities(), b.velocities()
+            scale = float(np.abs(va - vel).max())
+            out["parity_check"] = {"k": 1, "bits_equal": None, "max_abs_dr": float(np.abs(pa - pb).max()), "max_abs_dv": float(np.abs(va - vb).max()),
+                                   "max_abs_dv_over_max_dv": float(np.abs(va - vb).max() / scale) if scale > 0 else None,
+                                   "within_tolerance": bool(np.abs(va - vb).max() <= 1e-3 * scale and np.abs(pa - pb).max() <= 1e-3 * scale + 1e-5),
+                                   "against": "one STRICT step (= the reference's arithmetic, bit for bit) of the same initial state, all bodies; "
+                                              "FAST is the same law reassociated: the worst body (a neighbour at r ~ 1e-4) is held to 1e-3 of the "
+                                              "largest velocity change, as tests/test_gpu_ring.py holds it"}
+            a.sync(); b.sync()
+    return out
 
 
 def main():
@@ -221,6 +302,9 @@ def main():
     ap.add_argument("--no-ring", action="store_true",
                     help="multi-GPU FAST: keep the ordered fold with its one exchange per step instead of the pairs form on shards "
                          "(every unordered pair once, two exchanges per step)")
+    ap.add_argument("--fast-form", choices=["auto", "pairs", "pairs_overlapped", "ordered"], default="auto",
+                    help="multi-GPU --mode fast: the form a step takes -- auto (default): ShardedScene.choose_form times every form this "
+                         "shape can take on this machine and the timed region runs the fastest; or name one (ordered == --no-ring)")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="multi-GPU only: also time FAST with the exchange overlapped (ShardedScene(overlap=True)); off by default "
                          "so that nothing untried on hardware can cost the scaling run its exit code")
@@ -267,10 +351,39 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # what the communicator saw: the backend, the world, how many DISTINCT devices the ranks sit on (their
+    # UUIDs all-gathered: a rehearsal that shares one GPU says so), the collective library's version
+    def device_uuid():
+        try:
+            return str(torch.cuda.get_device_properties(device_index).uuid)
+        except Exception:   # (a torch without the attribute: the device's index and name still tell ranks on one GPU apart from ranks on eight)
+            return f"{os.uname().nodename}:{device_index}:{torch.cuda.get_device_name(device_index)}"
+
+    uuids = [device_uuid()]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, uuids[0])
+        uuids = gathered
+    try:
+        ccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:
+        ccl = f"unknown ({e.__class__.__name__})"
+    comm = {"backend": (backend if world > 1 else None), "backend_is": "torch.distributed 'nccl' = RCCL on ROCm" if backend == "nccl" else
+            "REHEARSAL backend (ranks may share devices; exchanges staged through the host)", "world": world,
+            "distinct_devices": len(set(uuids)), "device_uuids": uuids, "rccl_version": ccl,
+            "device": torch.cuda.get_device_name(device_index)}
+
     n = args.n
     pos, vel = nb.init_state(n, 1234)
     primary = nb.NB_MODE_STRICT if args.mode == "strict" else nb.NB_MODE_FAST
-    res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel, ring=False if args.no_ring else None)
+    # FAST on several GPUs: which form a step takes is decided by TIMING on this machine (the pairs form with its exchanges in sequence
+    # or behind compute, or the ordered fold), after both exchanges were verified on a known pattern -- no multi-GPU box saw this code
+    # before the driver's; --no-ring keeps the ordered fold outright
+    if args.fast_form == "ordered":
+        args.no_ring = True
+    named = {"pairs": False, "pairs_overlapped": True}.get(args.fast_form)   # None: auto / ordered
+    res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel, ring=False if args.no_ring else None, ring_overlap=named,
+                    choose=primary == nb.NB_MODE_FAST and not args.no_ring and args.fast_form == "auto", parity=True)
 
     def summarise(r, data="planar"):
         steps_per_s = r["steps"] / r["elapsed_s"]
@@ -329,10 +442,13 @@ def main():
                    "mode": args.mode,
                    "sharding": f"index range x{world}, all-gather of positions per step" +
                                (f"; every unordered pair evaluated once, the halves of the {res['partners']} ranks in front leaving in a second, "
-                                "point-to-point exchange per step" if res["partners"] else ""),
+                                "point-to-point exchange per step" + ("; both exchanges behind compute (the step in phases)" if res["ring_overlap"] else "")
+                                if res["partners"] else ""),
                    "tile": "library default"},
         "interactions_per_s": s["interactions_per_s"],
         "roofline": s["roofline"],
+        "parity_check": res.get("parity_check"),
+        "comm": dict(comm, exchange_paths=res["exchange_paths"], fast_form=res["form"]),
         # BASELINE.json's north_star asks for >= 40 % of the fp32 roofline AND |dr| < 1e-4 against the reference after 1 000
         # steps.  The system is chaotic: only arithmetic identical to the reference's holds the second
         # line, and an exact binary32 divide costs 4 vector ops where the flop count says 1, which caps STRICT near 1/3.
@@ -372,10 +488,10 @@ def main():
         except Exception as e:  # pragma: no cover
             line["other_mode"] = {"error": repr(e)}
 
-        if world > 1 and not (primary == nb.NB_MODE_FAST and res["partners"]):
+        if world > 1 and not (primary == nb.NB_MODE_FAST and res["partners"] and not res["ring_overlap"]):
             leg["name"] = "fast_pairs_on_shards"
             try:
-                r2 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel)
+                r2 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=False)
                 if r2["partners"]:
                     o = summarise(r2)
                     line["fast_pairs_on_shards"] = {"what": "FAST, every unordered pair evaluated once across the ranks: a rank folds its bodies "
@@ -386,7 +502,24 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["fast_pairs_on_shards"] = {"error": repr(e)}
 
-        if world > 1 and not args.no_ring:
+        if world > 1 and not (primary == nb.NB_MODE_FAST and res["ring_overlap"]):
+            # the same with both exchanges behind compute (the step in phases: nb_launch_ring_fold_phase)
+            leg["name"] = "fast_pairs_on_shards_overlapped"
+            try:
+                probe = nb.ShardedScene(pos, vel, nb.default_params(mode=nb.NB_MODE_FAST))
+                can = bool(probe.partners) and probe.backend.ring_phased(probe.params, probe.n, probe.first, probe.count)
+                del probe
+                if can:
+                    r3 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=True)
+                    o = summarise(r3)
+                    line["fast_pairs_on_shards_overlapped"] = {"what": "the pairs form on shards in phases: pairs inside the rank's own slot while the last "
+                                                                       "step's all-gather lands, every other pair, the second exchange beside the reduce of the "
+                                                                       "rank's own sums", "partners": r3["partners"], "value": o["body_updates_per_s"],
+                                                               "ms_per_step": o["ms_per_step"], "kernel_ms": o["kernel_ms"]}
+            except Exception as e:  # pragma: no cover
+                line["fast_pairs_on_shards_overlapped"] = {"error": repr(e)}
+
+        if world > 1 and not args.no_ring and primary != nb.NB_MODE_FAST:
             # which of the two FAST forms the MACHINE prefers: ShardedScene.choose_form times both on the state in hand (the slowest
             # rank's time counts) -- the answer a host gets when it asks instead of trusting the library's one-GPU line
             leg["name"] = "fast_form_chosen_by_timing"
@@ -633,6 +766,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # a line whose own parity check failed is still printed -- and the run does not look clean
+    pc = line.get("parity_check") or {}
+    if pc.get("bits_equal") is False or pc.get("within_tolerance") is False:
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -222,6 +222,10 @@ class ShardedScene:
         self.scratch = torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None
         self.cur = 0
         self.steps_done = 0
+        # how the two exchanges are issued (verify_exchanges() may move either to its fallback)
+        self.gather_in_place = True      # RCCL all-gather with this rank's slot of the receive buffer as the send buffer
+        self.ring_grouped = True         # the second exchange as ONE group of sends and receives (else: one group per distance)
+        self.exchange_report = None
         self.velfull = None      # boids only: replicas of ALL velocities (ping-pong), built on first use
         self._pvstage = None     # boids, world > 1: [world][pos slot | vel slot], what the one all-gather per step moves
         self.velfull_valid = False
@@ -232,8 +236,8 @@ class ShardedScene:
         lo = self.rank * slot
         mine = buf[lo:lo + slot]
         if self.dist.get_backend(self.group) == "nccl":
-            # RCCL, in place: the send buffer is this rank's slot of the receive buffer
-            return self.dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op)
+            # RCCL, in place: the send buffer is this rank's slot of the receive buffer (fallback: a copy of the slot)
+            return self.dist.all_gather_into_tensor(buf, mine if self.gather_in_place else mine.clone(), group=self.group, async_op=async_op)
         elif buf.device.type == "cpu":
             self.dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
         else:
@@ -259,7 +263,13 @@ class ShardedScene:
                 to, frm = dist.get_global_rank(self.group, to), dist.get_global_rank(self.group, frm)
             ops.append(dist.P2POp(dist.isend, sums[d * S:(d + 1) * S], to, self.group, tag=d))
             ops.append(dist.P2POp(dist.irecv, recv[(d - 1) * S:d * S], frm, self.group, tag=d))
-        return dist.batch_isend_irecv(ops), (recv if on_host else None)
+        if self.ring_grouped:
+            reqs = dist.batch_isend_irecv(ops)
+        else:   # fallback: one group per distance d -- every rank sends to rank + d and receives from rank - d, then the next d
+            reqs = []
+            for i in range(0, len(ops), 2):
+                reqs += dist.batch_isend_irecv(ops[i:i + 2])
+        return reqs, (recv if on_host else None)
 
     def _ring_exchange_wait(self, started) -> None:
         reqs, staged = started
@@ -270,6 +280,69 @@ class ShardedScene:
 
     def _ring_exchange(self) -> None:
         self._ring_exchange_wait(self._ring_exchange_start())
+
+    def verify_exchanges(self) -> dict:
+        """Before the first step of a world > 1: run both exchanges ONCE on a known per-rank pattern and check, on every rank, that
+        every record arrived where the step will read it (collective; one all-reduce per check so that all ranks agree).  The
+        in-place all-gather and the grouped sends / receives of the pairs form had run on a one-rank communicator and over gloo
+        only when this was written (no multi-GPU box in the build); a mismatch moves the exchange to its fallback -- the all-gather
+        from a copy of the slot, the second exchange as one group per distance, and, should that fail too, the ordered fold with its
+        one exchange -- without restarting anything.  Returns (and keeps as ``exchange_report``) which paths the steps will take.
+        Buffers used: the scratch side of the position ping-pong, ``sums`` / ``recv`` (every step overwrites them)."""
+        torch, dist = self.torch, self.dist
+        rep = {"world": self.world, "all_gather": None, "ring_exchange": None, "verified": False}
+        if self.world == 1:
+            self.exchange_report = rep
+            return rep
+        self._wait_pending()
+        on_device = dist.get_backend(self.group) == "nccl"
+
+        def agree(bad: bool) -> bool:   # True when ANY rank saw a mismatch
+            t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=self.device if on_device else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            return bool(t.item())
+
+        def pattern(rank, records, salt):   # four words per record that name the sending rank, the record and the exchange
+            i = torch.arange(records, dtype=torch.float32, device=self.device)
+            return torch.stack([i + 1000.0 * rank + salt, -i, torch.full_like(i, float(rank)), torch.full_like(i, float(salt))], dim=1)
+
+        # -- the all-gather: every slot of the buffer must hold its rank's pattern
+        buf = self.pos[self.cur ^ 1]
+        want = torch.cat([pattern(r, self.slot, 7.0) for r in range(self.world)])
+        for attempt in ("in_place", "out_of_place"):
+            self.gather_in_place = attempt == "in_place"
+            buf.fill_(float("nan"))
+            buf[self.rank * self.slot:(self.rank + 1) * self.slot] = want[self.rank * self.slot:(self.rank + 1) * self.slot]
+            self._all_gather_slots(buf)
+            if not agree(not torch.equal(buf, want)):
+                rep["all_gather"] = attempt
+                break
+        buf.zero_()
+        if rep["all_gather"] is None:
+            raise _lib.NbError(_lib.NB_ERR_STATE, "verify_exchanges: the all-gather does not deliver every rank's slot, in place or from a copy")
+        # -- the pairs form's second exchange: chunk d - 1 of recv must hold chunk d of rank - d's sums
+        if self.partners:
+            S = self.count
+            want = torch.cat([pattern((self.rank - d) % self.world, S, float(d)) for d in range(1, self.partners + 1)])
+            for attempt in ("grouped", "per_distance"):
+                self.ring_grouped = attempt == "grouped"
+                self.sums[:S].zero_()
+                for d in range(1, self.partners + 1):
+                    self.sums[d * S:(d + 1) * S] = pattern(self.rank, S, float(d))
+                self.recv.fill_(float("nan"))
+                self._ring_exchange()
+                if not agree(not torch.equal(self.recv, want)):
+                    rep["ring_exchange"] = attempt
+                    break
+            if rep["ring_exchange"] is None:   # neither form delivers: the ordered fold and its one exchange
+                rep["ring_exchange"] = "disabled"
+                self.partners, self.ring_overlap = 0, False
+                self.sums = self.recv = None
+                sb = self.backend.scratch_bytes(self.params, self.n, self.count) if self.count else 0
+                self.scratch = torch.empty((sb,), dtype=torch.uint8, device=self.device) if sb else None
+        rep["verified"] = True
+        self.exchange_report = rep
+        return rep
 
     def _wait_pending(self) -> None:
         """overlap: make the current stream wait for the exchange in flight (no host wait with RCCL)"""

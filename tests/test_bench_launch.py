@@ -51,8 +51,17 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     pairs = line["fast_pairs_on_shards"]
     assert pairs["partners"] == 1 and pairs["roofline"]["kernel"] == "step_fast_ring_kernel" and pairs["value"] > 0
     assert 0 < pairs["roofline"]["frac"] < 1 and pairs["roofline"]["frac_nominal"] > pairs["roofline"]["frac"]
+    over = line["fast_pairs_on_shards_overlapped"]   # the same in phases, both exchanges behind compute
+    assert over["partners"] == 1 and over["value"] > 0 and over["kernel_ms"] > 0
     chosen = line["fast_form_chosen_by_timing"]
-    assert chosen["chosen"] in ("pairs", "ordered") and set(chosen["ms_per_step"]) == {"pairs", "ordered"}
+    assert chosen["chosen"] in ("pairs", "pairs_overlapped", "ordered") and set(chosen["ms_per_step"]) == {"pairs", "pairs_overlapped", "ordered"}
+    # the line proves its own parity: after preheat + warm-up + timed steps on TWO ranks every bit of the state is the CPU oracle's at
+    # that step (tests/golden/nbody_golden_c3.npz), and it says what the communicator saw
+    pc = line["parity_check"]
+    assert pc["bits_equal"] is True and pc["k"] == line["preheat"]["steps"] + 1 + 2 and pc["checksums"]["xor"] == pc["checksums"]["golden_xor"]
+    comm = line["comm"]
+    assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["distinct_devices"] == 1 and len(comm["device_uuids"]) == 2
+    assert comm["exchange_paths"] == {"world": 2, "all_gather": "in_place", "ring_exchange": None, "verified": True}
     assert set(line["unpreheated"]) >= {"strict", "fast"}
     assert line["boids_controller"]["split_form"]["value"] > 0
 
@@ -62,8 +71,8 @@ def test_gpus_4_mode_fast_rehearsal_takes_the_pairs_form_as_the_headline():
     """`bench.py --gpus 4 --mode fast` on the one GPU of the test box: four ranks share the device, both of the
     step's exchanges go through gloo -- the all-gather and the point-to-point one to the TWO ranks in front.  The headline of that
     line is the pairs form on shards; no scaling number is claimed."""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--mode", "fast", "--steps", "2", "--warmup", "1", "--preheat-ms", "20",
-                        "--no-cpu-baseline", "--no-secondary"],
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--mode", "fast", "--fast-form", "pairs", "--steps", "2", "--warmup", "1",
+                        "--preheat-ms", "20", "--no-cpu-baseline", "--no-secondary"],
                        env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -76,6 +85,34 @@ def test_gpus_4_mode_fast_rehearsal_takes_the_pairs_form_as_the_headline():
     n = 131072
     assert 0.95 < line["roofline"]["pair_evaluations_per_launch"] / (n * n / 8) < 1.05
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["frac_nominal"] > 1.8 * line["roofline"]["frac"]
+    # FAST's own parity check: one step of this form against one STRICT step, all bodies; both exchanges verified on a pattern first
+    pc = line["parity_check"]
+    assert pc["within_tolerance"] is True and pc["max_abs_dr"] < 1e-4 and pc["k"] == 1
+    assert line["comm"]["exchange_paths"] == {"world": 4, "all_gather": "in_place", "ring_exchange": "grouped", "verified": True}
+    assert line["comm"]["world"] == 4 and line["comm"]["distinct_devices"] == 1
+
+
+@pytest.mark.gpu
+def test_gpus_4_mode_fast_rehearsal_chooses_its_form_by_timing_and_runs_the_phases():
+    """`bench.py --gpus 4 --mode fast` as the driver would start it (--fast-form auto): after both exchanges were verified on a
+    pattern, ShardedScene.choose_form times the pairs form with its exchanges in sequence and behind compute and the ordered fold, the
+    timed region runs the fastest, and the line says which and what each cost.  Then the same with the overlapped form named: the
+    step in phases as the headline.  (Four ranks: the pool's process guard allows six processes on a card, so the world of eight is
+    rehearsed as threads -- tests/test_gpu_native_shard.py -- and over gloo on the CPU -- tests/test_dist_gloo.py.)"""
+    base = [sys.executable, BENCH, "--gpus", "4", "--mode", "fast", "--steps", "2", "--warmup", "1", "--preheat-ms", "20", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(base, env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    form = line["comm"]["fast_form"]
+    assert form["chosen"] in ("pairs", "pairs_overlapped", "ordered") and set(form["ms_per_step"]) == {"pairs", "pairs_overlapped", "ordered"}
+    ring = line["roofline"]["kernel"] == "step_fast_ring_kernel"
+    assert ring == (form["chosen"] != "ordered") and line["parity_check"]["within_tolerance"] is True
+    r = subprocess.run(base + ["--fast-form", "pairs_overlapped"], env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["roofline"]["kernel"] == "step_fast_ring_kernel" and "behind compute" in line["config"]["sharding"]
+    assert "ring_planes_kernel" in line["roofline"]["kernels_per_step"] and line["roofline"]["kernel_ms"] > 0
+    assert line["parity_check"]["within_tolerance"] is True and line["comm"]["fast_form"] is None
 
 
 def _preheat_rank(rank, world, port, out_dir):

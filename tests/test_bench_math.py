@@ -81,3 +81,28 @@ def test_committed_traffic_knows_the_shapes_of_a_multi_gpu_job(tmp_path, monkeyp
     assert bench.committed_traffic(nb, ["ring_reduce_kernel"], 131072, 16384)[0] is None                          # kernel not measured
     stale = types.SimpleNamespace(_lib=types.SimpleNamespace(kernel_code_sha=lambda: "other"))
     assert bench.committed_traffic(stale, ["step_strict_bc_kernel", "planes_kernel"], 131072, 16384)[0] is None   # other device code
+
+
+def test_the_bench_lines_own_parity_check(oracle):
+    """bench.py's `parity_check`: the final STRICT state of the headline set is held to the golden checksums of
+    exactly the step it reached.  Here on the CPU: the oracle's own state after step 1 and step 2 of N = 131 072 passes (the AVX2
+    batches are bit-identical to the scalar loop: tests/test_oracle.py), one flipped bit in one velocity fails, a step the file does
+    not hold or another set says so instead of claiming anything."""
+    import numpy as np
+
+    pos, vel = oracle.init_state(N, 1234)
+    p, v = oracle.run(pos, vel, 1, batched=True)
+    ok = bench.parity_against_golden(N, 1234, 1, p, v)
+    assert ok["bits_equal"] is True and ok["k"] == 1 and ok["checksums"]["xor"] == ok["checksums"]["golden_xor"]
+    # the helper's checksums are the test suite's (tests/test_gpu_parity.py:_checksums): XOR and wrapping sum of every word
+    u = p.view(np.uint32).ravel()
+    assert bench.state_checksums(p, v)[0][0] == int(np.bitwise_xor.reduce(u)) and bench.state_checksums(p, v)[1][0] == int(u.sum(dtype=np.uint64) & 0xFFFFFFFF)
+    bad = v.copy()
+    bad.view(np.uint32)[77, 1] ^= 1
+    assert bench.parity_against_golden(N, 1234, 1, p, bad)["bits_equal"] is False
+    assert bench.parity_against_golden(N, 1234, 2, p, v)["bits_equal"] is False          # the right bits of the wrong step
+    p2, v2 = oracle.run(p, v, 1, batched=True)
+    assert bench.parity_against_golden(N, 1234, 2, p2, v2)["bits_equal"] is True
+    for k, n, seed in ((0, N, 1234), (1001, N, 1234), (5, 4096, 1234), (5, N, 99)):
+        r = bench.parity_against_golden(n, seed, k, p[:n], v[:n])
+        assert r["bits_equal"] is None and "why" in r

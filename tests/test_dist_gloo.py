@@ -250,3 +250,63 @@ def test_choose_form_times_both_forms_and_every_rank_agrees(tmp_path, oracle, wo
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
+
+
+def _verify_worker(rank, world, port, n, k, out_dir, broken):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nenbody_amd
+        import oracle
+        from oracle_backend import OracleBackend
+
+        pos, vel = oracle.init_state(n, seed=4321)
+        pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+        sc = nenbody_amd.ShardedScene(pos, vel, nenbody_amd.default_params(mode=nenbody_amd.NB_MODE_FAST), backend=OracleBackend(), device="cpu",
+                                      ring=True, ring_overlap=True)
+        real_batch = dist.batch_isend_irecv
+
+        def faulty(ops):   # a second exchange that loses data: what arrives is overwritten (one rank is enough to move every rank)
+            reqs = real_batch(ops)
+            if (broken == "grouped" and len(ops) > 2) or broken == "all":
+                for r in reqs:
+                    r.wait()
+                if rank == 0:
+                    for op in ops:
+                        if op.op is dist.irecv:
+                            op.tensor.add_(1.0)
+                return []    # (all waited for: a gloo receive must not be waited for twice)
+            return reqs
+
+        if broken:
+            dist.batch_isend_irecv = faulty
+        rep = sc.verify_exchanges()
+        dist.batch_isend_irecv = real_batch if broken != "all" else faulty
+        want = {None: "grouped", "grouped": "per_distance", "all": "disabled"}[broken]
+        if world == 2 and broken == "grouped":
+            want = "grouped"    # (one partner: the group IS one send and one receive -- nothing to fall back from)
+        assert rep["verified"] and rep["all_gather"] == "in_place" and rep["ring_exchange"] == want, rep
+        assert sc.exchange_report is rep and (sc.partners == 0) == (want == "disabled") and sc.ring_grouped == (want == "grouped")
+        sc.step_n(k)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,broken", [(3, 48, None), (4, 64, "grouped"), (3, 48, "all"), (8, 64, "grouped")])
+def test_exchanges_are_verified_on_a_pattern_and_fall_back(tmp_path, oracle, world, n, broken):
+    """ShardedScene.verify_exchanges: before the first step both exchanges move a known per-rank pattern and every rank checks what
+    arrived (one all-reduce per check: all ranks agree on the verdict).  A second exchange that loses data when issued as one group
+    moves to one group per distance; one that loses data either way is dropped for the ordered fold and its one exchange -- and the
+    steps that follow are right in every case."""
+    k = 2
+    mp.spawn(_verify_worker, args=(world, _free_port(), n, k, str(tmp_path), broken), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, seed=4321)
+    pos[:, 2] = np.linspace(-1, 1, n, dtype=np.float32)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert np.abs(got["pos"] - p_ref).max() <= 2e-5 and np.abs(got["vel"] - v_ref).max() <= 1e-6
