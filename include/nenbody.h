@@ -359,6 +359,22 @@ int nb_shard_set_boids_split(nb_shard *sh, int on);
  * kernel -> exchange in sequence.  Host-supplied exchanges (nb_shard_use_gather / nb_shard_use_ring) receive the second stream
  * and must order their work on it. */
 int nb_shard_set_overlap(nb_shard *sh, int on);
+/* Both exchanges of a step, ONCE, on a known per-rank pattern, checked on every rank (collective; the ranks agree on every verdict
+ * through a third collective: ncclAllReduce, or the host's gather).  A mismatch moves the exchange to its fallback without restarting
+ * anything: the all-gather from a copy of the slot (*gather_path 1; 0: in place), the second exchange as one group per distance
+ * (*ring_path 1; 0: one group), then not at all (*ring_path 2: the ordered fold and its one exchange); *ring_path -1: no pairs form
+ * planned.  Either pointer may be NULL.  A world of one answers at once.  With RCCL on more than one rank the first nb_shard_step runs
+ * this by itself if the host has not. */
+int nb_shard_verify_exchanges(nb_shard *sh, int *gather_path, int *ring_path);
+/* Which form should a FAST step take on THIS machine?  Times `steps` steps (0: four) of every form the shard can take -- 1: the pairs
+ * form with its two exchanges in sequence, 2: the same in phases with the exchanges behind compute (nb_shard_set_overlap), 0: the
+ * ordered fold with its one exchange -- on the state in hand, takes the slowest rank's time of each (collective), keeps the fastest
+ * for the steps to come (*chosen) and puts the state back; ms3 (NULL or three doubles): milliseconds per step of forms 0, 1, 2
+ * (negative: not offered).  The library's own line for the pairs form (nb_ring_partners) was drawn from one-GPU timings; this asks
+ * the machine.  With RCCL on more than one rank the first nb_shard_step asks by itself unless the host has decided
+ * (nb_shard_set_pairs) or asked (this call).  Note: which form runs decides the rounding of FAST's sums -- a host that needs
+ * run-to-run identical bits names the form. */
+int nb_shard_choose_form(nb_shard *sh, uint32_t steps, int *chosen, double *ms3);
 /* 1 where a step of this shard takes the pairs form in phases with both exchanges on the second stream, else 0. */
 int nb_shard_pairs_overlapped(const nb_shard *sh);
 /* This rank's index range. */

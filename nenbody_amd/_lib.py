@@ -137,6 +137,8 @@ PROTOTYPES = {
     "nb_shard_set_pairs": (c_int, [c_void_p, c_int]),
     "nb_shard_pairs_partners": (c_int, [c_void_p]),
     "nb_shard_pairs_overlapped": (c_int, [c_void_p]),
+    "nb_shard_verify_exchanges": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "nb_shard_choose_form": (c_int, [c_void_p, c_uint32, POINTER(c_int), POINTER(ctypes.c_double)]),
     "nb_shard_set_boids_split": (c_int, [c_void_p, c_int]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),
     "nb_shard_upload": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -142,6 +142,10 @@ hipError_t launch_libm_selftest(int fn, uint32_t first, uint32_t count, uint32_t
 hipError_t launch_valu_stream(int mix, uint32_t blocks, uint32_t trips, float *sink, unsigned long long *stamps, hipStream_t s);
 // sharded boids: the gathered staging buffer [world][pos slot | vel slot] -> position and velocity replicas (world * slot records each)
 hipError_t launch_unstage(uint32_t slot, uint32_t world, const float4 *stage, float4 *pos, float4 *vel, hipStream_t s);
+// the exchanges verified on a pattern (nb_shard_verify_exchanges): record i = (i + 1000 rank + salt, -i, rank, salt), or NaN; the
+// check adds the number of records that differ to *mismatches
+hipError_t launch_exchange_pattern(float4 *dst, uint32_t count, float rank, float salt, bool fill_nan, hipStream_t s);
+hipError_t launch_exchange_check(const float4 *src, uint32_t count, float rank, float salt, uint32_t *mismatches, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

@@ -634,6 +634,21 @@ class NativeShard:
         """does a step take the pairs form in phases, both exchanges on a second stream (``nb_shard_pairs_overlapped``)?"""
         return int(self._lib.nb_shard_pairs_overlapped(self._sh)) == 1
 
+    def verify_exchanges(self):
+        """both exchanges once on a known pattern, checked on every rank (``nb_shard_verify_exchanges``; collective): returns
+        (gather_path, ring_path) -- 0 / 1: in place / from a copy; -1 / 0 / 1 / 2: no pairs form / one group / one group per
+        distance / dropped for the ordered fold"""
+        g, r = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.nb_shard_verify_exchanges(self._sh, ctypes.byref(g), ctypes.byref(r)))
+        return g.value, r.value
+
+    def choose_form(self, steps: int = 4):
+        """times every form a FAST step of this shard can take on this machine and keeps the fastest (``nb_shard_choose_form``;
+        collective): returns (chosen, [ms per step of the ordered fold, the pairs form, the pairs form overlapped]; < 0: not offered)"""
+        c, ms = ctypes.c_int(), (ctypes.c_double * 3)()
+        self._check(self._lib.nb_shard_choose_form(self._sh, int(steps), ctypes.byref(c), ms))
+        return c.value, list(ms)
+
     def upload(self, positions, velocities) -> None:
         """Replaces the state (all n positions, all n velocities; the rank keeps its own range of the latter)."""
         pos = np.ascontiguousarray(positions, dtype=np.float32)

@@ -149,7 +149,8 @@ def _hip_runtime():
     return hip
 
 
-def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None, force_pairs=False):
+def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None, force_pairs=False,
+                 verify=None):
     import sys
 
     from conftest import ROOT
@@ -197,17 +198,36 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
                 ops.append(dist.P2POp(dist.irecv, got[(d - 1) * chunk_bytes:d * chunk_bytes], (rank - d) % world, tag=d))
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if verify == "lossy_ring" and rank == 0:   # a second exchange that loses data on one rank: every rank must drop the pairs form
+                got[:16] = 0
             assert hip.hipMemcpy(recv, got.data_ptr(), partners * chunk_bytes, 1) == 0
             ring_calls.append(partners)
 
         pos, vel = state3d(oracle, n, seed=n) if seed is None else oracle.init_state(n, seed)
         with nenbody_amd.NativeShard(pos, vel, nenbody_amd.default_params(mode=mode), rank=rank, world=world,
                                      gather=gather, overlap=overlap, ring=ring if with_ring else None) as sh:
+            extra = {}
+            if verify:   # both exchanges on a known pattern first, then the machine is asked which form to take
+                before = sh.partners
+                paths = sh.verify_exchanges()
+                assert paths == ((0, 2) if verify == "lossy_ring" else (0, 0 if before else -1)), paths
+                assert sh.partners == (0 if verify == "lossy_ring" else before)
+                sh.step(1)   # (a state that is not the upload's: choose_form must put THIS one back)
+                p0, v0 = sh.positions(), sh.local_velocities()
+                chosen, ms = sh.choose_form(2)
+                assert (sh.positions().view(np.uint32) == p0.view(np.uint32)).all() and (sh.local_velocities().view(np.uint32) == v0.view(np.uint32)).all()
+                if before and verify != "lossy_ring":
+                    assert chosen in (0, 1, 2) and ms[0] > 0 and ms[1] > 0 and ms[2] > 0 and ms[chosen] == min(ms), (chosen, ms)
+                    assert sh.partners == (0 if chosen == 0 else before) and sh.pairs_overlapped == (chosen == 2)
+                else:
+                    assert chosen == 0 and sh.partners == 0
+                extra = dict(chosen=chosen, ms=np.array(ms))
+                calls.clear(), ring_calls.clear()
             partners, overlapped = sh.partners, sh.pairs_overlapped
             drive(sh, schedule or SCHEDULE)
             np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sh.positions(), vel=sh.local_velocities(),
                      inst=sh.local_instances(), first=sh.first, count=sh.count, calls=len(calls), ring_calls=len(ring_calls),
-                     partners=partners, overlapped=overlapped)
+                     partners=partners, overlapped=overlapped, **extra)
     finally:
         dist.destroy_process_group()
 
@@ -299,6 +319,34 @@ def test_fast_shards_in_the_pairs_form_with_a_second_exchange(tmp_path, nb, orac
             assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r} velocities: {np.quantile(dv, 0.999) / scale:.2e} {dv.max() / scale:.2e}"
             dp = np.abs(got["pos"] - p_ref).max(axis=1)
             assert np.quantile(dp, 0.999) <= 2e-4 * scale and dp.max() <= 2e-2 * scale, f"rank {r} positions (replica)"
+
+
+@pytest.mark.parametrize("world,n,verify", [(2, 32768, "ok"), (4, 32768, "ok"), (3, 49152, "lossy_ring")])
+def test_native_shard_verifies_its_exchanges_and_asks_the_machine_for_the_form(tmp_path, nb, oracle, world, n, verify):
+    """nb_shard_verify_exchanges + nb_shard_choose_form (the native shard had no way to find out whether the pairs form
+    pays -- or works -- between real GPUs): both exchanges move a known pattern and every rank checks what arrived, the ranks agreeing
+    on the verdict through the host's gather; then every form the shard can take is timed on the state in hand (slowest rank), the
+    fastest kept, the state put back bit for bit.  With a second exchange that loses data on one rank, every rank drops the pairs form
+    for the ordered fold.  The steps that follow are the oracle's to FAST's tolerance either way."""
+    import torch.multiprocessing as mp
+
+    schedule = (("nbody", 2),)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(tmp_path), False, schedule, True, 77, True, verify), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, 77)
+    p_ref, v_ref = reference(oracle, pos, vel, (("nbody", 3),))     # (one step before the choice, two after)
+    chosen = set()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        first, count = int(got["first"]), int(got["count"])
+        chosen.add(int(got["chosen"]))
+        scale = float(np.abs(v_ref - vel).max())
+        dv = np.abs(got["vel"] - v_ref[first:first + count]).max(axis=1)
+        assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r} velocities"
+        assert int(got["ring_calls"]) == (2 if int(got["partners"]) else 0)
+    assert len(chosen) == 1     # every rank took the same form
 
 
 def test_native_shard_boids_split_form(nb, oracle):
