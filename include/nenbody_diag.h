@@ -81,6 +81,12 @@ int nb_debug_reload_env(void);
  * process switch, deliberately not an environment variable: nothing a deployment inherits can arm it. */
 int nb_diag_rccl_solo(int on);
 
+/* 1: this library holds every launch shape the diagnostic knobs can name (libnenbody_hip_legacy.so: the same sources with
+ * -DNB_LEGACY_FORMS, `make -C nenbody_amd/csrc legacy`); 0: the product build, which holds the shapes the library's plan reaches by
+ * itself and answers NB_ERR_UNSUPPORTED where a knob names another (producer/consumer and j-parallel STRICT shapes, the
+ * workgroup-tile FAST form, wave counts other than eight, ...). */
+int nb_diag_legacy_forms(void);
+
 /* The kernels one step of this shape launches, dominant one first, comma separated ("step_strict_bc_kernel,planes_kernel"),
  * as the library itself plans the launch (make_plan): what bench.py labels its roofline with. */
 int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t count, char *out, size_t out_bytes);

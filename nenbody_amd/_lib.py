@@ -162,6 +162,7 @@ DIAG_PROTOTYPES = {
     "nb_debug_reload_env": (c_int, []),
     "nb_diag_enable_env": (c_int, [c_int]),
     "nb_diag_rccl_solo": (c_int, [c_int]),
+    "nb_diag_legacy_forms": (c_int, []),
     "nb_diag_plan": (c_int, [POINTER(NbParams), c_uint32, c_uint32, ctypes.c_char_p, c_size_t]),
 }
 
@@ -195,27 +196,51 @@ def _preload_torch_hip_runtime() -> None:
         pass
 
 
-def load() -> ctypes.CDLL:
-    """Load libnenbody_hip.so (built by nenbody_amd/csrc/Makefile or __graft_entry__.build())."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+_loaded = {}   # path -> bound CDLL
+
+
+def _bind(path: str) -> ctypes.CDLL:
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C nenbody_amd/csrc` (hipcc, gfx950). "
+            f"{path} is missing: build it with `make -C nenbody_amd/csrc` (hipcc, gfx950). "
             "nenbody_amd has no CPU fallback."
         )
     _preload_torch_hip_runtime()
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in list(PROTOTYPES.items()) + list(DIAG_PROTOTYPES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
     got = lib.nb_abi_version()
     if got != NB_ABI_VERSION:
-        raise ImportError(f"libnenbody_hip.so ABI {got} != binding ABI {NB_ABI_VERSION}")
-    _lib = lib
+        raise ImportError(f"{os.path.basename(path)} ABI {got} != binding ABI {NB_ABI_VERSION}")
+    _loaded[path] = lib
     return lib
+
+
+def load() -> ctypes.CDLL:
+    """Load libnenbody_hip.so (built by nenbody_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+# Test infrastructure: the product library holds the launch shapes its own plan reaches; the shapes only the diagnostic knobs can
+# name (NB_STRICT_PC, NB_FAST_WAVES, ...: rounds 1-3's measurement history) live in libnenbody_hip_legacy.so, the same sources built
+# with -DNB_LEGACY_FORMS (`make -C nenbody_amd/csrc legacy`).  The test suite binds it for the tests that name such a shape.
+LEGACY_LIB_PATH = os.path.join(_HERE, "lib", "libnenbody_hip_legacy.so")
+
+
+def use_library(path=None) -> str:
+    """Bind another build of the library for the calls that follow (None: back to LIB_PATH); returns the path that was bound.
+    Objects created before the switch keep the library they were created with."""
+    global _lib
+    before = next((p for p, lib in _loaded.items() if lib is _lib), LIB_PATH)
+    _lib = _bind(path or LIB_PATH)
+    return before
 
 
 # the sources that define the kernels bench.py times and profiles/hbm_traffic.json meters (the two whole-set folds, the block

@@ -588,6 +588,12 @@ int launch_step_planned(const nb_params &p, const Plan &pl, uint32_t n_total, ui
                                               : pl.fsl   ? nbk::launch_fast_sl(a, pl.ib, pl.slices, scratch, stream)
                                               : pl.waves ? nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, stream)
                                                          : nbk::launch_fast(a, pl.tile, pl.ib, pl.groups, pl.slices, stream);
+    if (e == hipErrorNotSupported) {  // a launch shape only the diagnostic knobs can name, in a build without -DNB_LEGACY_FORMS
+        *err = "nb: this launch shape is one of the legacy forms (NB_STRICT_PC / NB_STRICT_LANES / NB_STRICT_UNROLL / NB_STRICT_SL=2,3 / "
+               "NB_FAST_WAVES / NB_FAST_GROUPS / NB_FAST_PAIRS_W): this library was built without them (make -C nenbody_amd/csrc legacy "
+               "builds libnenbody_hip_legacy.so, which holds every form)";
+        return NB_ERR_UNSUPPORTED;
+    }
     if (e != hipSuccess) {
         *err = std::string("nb: kernel launch failed: ") + hipGetErrorString(e);
         return NB_ERR_HIP;
@@ -2610,6 +2616,17 @@ NB_EXPORT int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, u
         if (rc != NB_OK) return rc;
     }
     return launch_ring_finish_planned(p, *rp, n_total, first, count, pos_in, pos_out, vel, sums, recv, (hipStream_t)stream, &g_tls_error);
+}
+
+// 1: this library holds every launch shape the diagnostic knobs can name (built with -DNB_LEGACY_FORMS: make legacy); 0: the product
+// build, which holds the shapes make_plan reaches by itself
+NB_EXPORT int nb_diag_legacy_forms(void)
+{
+#ifdef NB_LEGACY_FORMS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 NB_EXPORT int nb_diag_rccl_solo(int on)

@@ -46,10 +46,27 @@ def monkeypatch():
         if _lib._lib is not None:  # only once the library is loaded; a fresh load reads the environment itself
             _lib._lib.nb_debug_reload_env()
 
+    def names_a_legacy_form(name, value):
+        """the launch shapes only these knobs can name are not in the product library: the test that sets one
+        runs against libnenbody_hip_legacy.so -- the same sources built with -DNB_LEGACY_FORMS -- until the patch is undone"""
+        v = str(value)
+        return ((name == "NB_STRICT_PC" and v != "0") or (name == "NB_STRICT_LANES" and v in ("2", "4", "8")) or name == "NB_STRICT_UNROLL"
+                or (name == "NB_FAST_WAVES" and v != "8") or name == "NB_FAST_GROUPS" or name == "NB_FAST_PAIRS_W"
+                or (name == "NB_STRICT_SL" and v in ("2", "3")))
+
     class NbMonkeyPatch(MonkeyPatch):
+        _switched = False
+
         def setenv(self, name, value, prepend=None):
             super().setenv(name, value, prepend)
             if name.startswith("NB_"):
+                if names_a_legacy_form(name, value) and not self._switched:
+                    import nenbody_amd._lib as _lib
+
+                    if not os.path.exists(_lib.LEGACY_LIB_PATH):
+                        pytest.skip("libnenbody_hip_legacy.so is not built (make -C nenbody_amd/csrc legacy)")
+                    _lib.use_library(_lib.LEGACY_LIB_PATH)
+                    self._switched = True
                 reload()
 
         def delenv(self, name, raising=True):
@@ -59,6 +76,11 @@ def monkeypatch():
 
         def undo(self):
             super().undo()
+            if self._switched:
+                import nenbody_amd._lib as _lib
+
+                _lib.use_library(None)
+                self._switched = False
             reload()
 
     mp = NbMonkeyPatch()

@@ -244,6 +244,8 @@ def test_debug_overrides_are_read_once_and_reloaded_on_request(nb, monkeypatch):
     assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == auto
     monkeypatch.setenv("NB_FAST_SLICES", "1")   # the fixture reloads by itself
     monkeypatch.setenv("NB_FAST_GROUPS", "4")
+    lib = _lib.load()   # (a legacy form: the fixture has bound libnenbody_hip_legacy.so, which holds it -- tests/conftest.py)
+    assert lib.nb_diag_legacy_forms() == 1
     assert lib.nb_scratch_bytes(ctypes.byref(fast), 131072, 16384) == 0   # (an LDS form, named by its groups) the j chunks meet in LDS: nothing through memory
     strict = nb.default_params()
     monkeypatch.setenv("NB_STRICT_BC", "0")

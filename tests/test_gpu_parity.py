@@ -1610,6 +1610,33 @@ def test_perf_floor_of_the_whole_set_kernels(nb, capsys):
         assert v <= f * slack, f"{k}: {v:.3f} ms per step, floor {f} x {slack}"
 
 
+def test_the_product_library_refuses_the_legacy_forms_by_name(nb, oracle):
+    """The product library holds the launch shapes its own plan reaches; a shape only a diagnostic knob can name (here the
+    producer/consumer STRICT form and the workgroup-tile FAST form of round 1) is answered with NB_ERR_UNSUPPORTED and a message that
+    says where it lives -- never with another kernel.  (The knob is set behind the fixture's back: the fixture would bind the legacy
+    build.)"""
+    from nenbody_amd import _lib
+
+    assert _lib.load().nb_diag_legacy_forms() == 0, "the default binding must be the product library"
+    pos, vel = oracle.init_state(4096, 3)
+    for knob, value, mode in (("NB_STRICT_PC", "14", nb.NB_MODE_STRICT), ("NB_FAST_WAVES", "0", nb.NB_MODE_FAST)):
+        os.environ[knob] = value
+        nb.reload_env()
+        try:
+            with pytest.raises(nb.NbError) as e:
+                with nb.Scene(pos, vel, nb.default_params(mode=mode)) as sc:
+                    sc.step_n(1)
+                    sc.sync()
+            assert e.value.status == _lib.NB_ERR_UNSUPPORTED and "legacy" in str(e.value)
+        finally:
+            del os.environ[knob]
+            nb.reload_env()
+    with nb.Scene(pos, vel) as sc:   # ... and the library is none the worse for it
+        sc.step_n(2)
+        p, _ = sc.state()
+    assert_bits_equal(p, oracle.run(pos, vel, 2)[0])
+
+
 def test_contexts_on_concurrent_host_threads(nb, oracle):
     """A context is single-owner (`Scene: Send`, not `Sync`), but DIFFERENT contexts may be driven from
     different host threads at the same time -- each has its own stream, plans are cached per thread, the last error is

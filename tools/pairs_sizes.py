@@ -8,6 +8,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nenbody_amd as nb  # noqa: E402
+nb._lib.use_library(nb._lib.LEGACY_LIB_PATH)   # this script names launch shapes only the legacy build holds (make -C nenbody_amd/csrc legacy)
 nb.reload_env()  # tools/ read the NB_* kernel-form knobs; a host that merely loads the library does not (nb_diag_enable_env)
 
 sizes = [int(x) for x in sys.argv[1:]] or [8192, 16384, 24576, 32768, 49152, 65536, 81920, 98304, 114688, 131072, 196608, 262144]

@@ -47,17 +47,17 @@ class SoloScene(nb.ShardedScene):
         mine = buf[: self.slot]
         return self.dist.all_gather_into_tensor(mine, mine, async_op=async_op)
 
-    def _ring_exchange(self):
+    def _ring_exchange_start(self):
         # the pairs form's second exchange: torch refuses a send to oneself, so the one-rank group moves the D chunks through RCCL's
         # all-to-all instead (the same bytes through the same library; the native path below does send to itself)
-        self.dist.all_to_all_single(self.recv, self.sums[self.count:])
+        return [self.dist.all_to_all_single(self.recv, self.sums[self.count:], async_op=True)], None
 
 
-def python_path(mode, exchange=True, overlap=False, ring=False):
-    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0, overlap=overlap, ring=ring)
+def python_path(mode, exchange=True, overlap=False, ring=False, ring_overlap=False):
+    sc = SoloScene(pos, vel, nb.default_params(mode=mode), world=world, rank=0, overlap=overlap, ring=ring, ring_overlap=ring_overlap if ring else None)
     if not exchange:
         sc._all_gather_slots = lambda buf, async_op=False: None
-        sc._ring_exchange = lambda: None
+        sc._ring_exchange_start = lambda: ([], None)
     if ring:  # two launch calls per step: device time = events around the whole loop with the exchanges off
         assert sc.partners
         for _ in range(10):
@@ -111,7 +111,7 @@ def python_path(mode, exchange=True, overlap=False, ring=False):
 def native_path(mode, overlap=False, pairs=False):
     nb.load().nb_diag_rccl_solo(1)   # a communicator of one rank whatever `world` is (include/nenbody_diag.h)
     sh = nb.NativeShard(pos, vel, nb.default_params(mode=mode), rank=0, world=world, comm_id=nb.comm_id(), overlap=overlap, pairs=pairs)
-    assert bool(sh.partners) == pairs
+    assert bool(sh.partners) == pairs and sh.pairs_overlapped == (pairs and overlap)
     sh.step(10)
     sh.sync()
     t0 = time.perf_counter()
@@ -147,4 +147,13 @@ for name, mode in (("STRICT", nb.NB_MODE_STRICT), ("FAST", nb.NB_MODE_FAST)):
         print(f"{name:6s} ShardedScene pairs form, no exchange      : wall/step {w_rn * 1e6:8.1f} us", flush=True)
         print(f"{name:6s} ShardedScene pairs form + both exchanges  : wall/step {w_r * 1e6:8.1f} us  (+{(w_r - w_rn) * 1e6:.1f} us)", flush=True)
         print(f"{name:6s} NativeShard  pairs form + both exchanges  : wall/step {w_cr * 1e6:8.1f} us  (+{(w_cr - w_rn) * 1e6:.1f} us)", flush=True)
+        # the same step in PHASES (round 5): pairs inside the rank's own slot while the all-gather lands, the second exchange beside the
+        # reduce of the rank's own sums -- on one GPU with nothing on the wire: what the split itself costs
+        w_on, dev_o = python_path(mode, exchange=False, ring=True, ring_overlap=True)
+        w_o, _ = python_path(mode, ring=True, ring_overlap=True)
+        w_co = native_path(mode, overlap=True, pairs=True)
+        print(f"{name:6s} pairs form in phases: dev/step {dev_o * 1e6:8.1f} us (events around the loop, exchanges off)  ({(dev_o - dev_r) * 1e6:+.1f} us against the one-launch fold)", flush=True)
+        print(f"{name:6s} ShardedScene in phases, no exchange       : wall/step {w_on * 1e6:8.1f} us", flush=True)
+        print(f"{name:6s} ShardedScene in phases + both exchanges   : wall/step {w_o * 1e6:8.1f} us  ({(w_o - w_r) * 1e6:+.1f} us against the exchanges in sequence)", flush=True)
+        print(f"{name:6s} NativeShard  in phases + both exchanges   : wall/step {w_co * 1e6:8.1f} us  ({(w_co - w_cr) * 1e6:+.1f} us against the exchanges in sequence)", flush=True)
 dist.destroy_process_group()
