@@ -259,7 +259,8 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps if sc.count and used[0] == len(ev) else 0.0
     kernels = (["step_fast_ring_kernel", "planes_kernel" if not sc.ring_overlap else "ring_planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"] if sc.partners
                else step_kernels(nb, mode, sc.n, sc.count))
-    out = {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
+    each = [sum(a.elapsed_time(b) for a, b in ev[i * per_step:(i + 1) * per_step]) for i in range(steps)] if sc.count and used[0] == len(ev) else []
+    out = {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "kernel_ms_each": each, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
            "kernels": kernels, "mode": "fast" if mode == nb.NB_MODE_FAST else "strict", "partners": sc.partners, "world": world,
            "ring_overlap": bool(sc.ring_overlap), "exchange_paths": exchange_paths, "form": form}
     if parity:
@@ -537,7 +538,8 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["fast_form_chosen_by_timing"] = {"error": repr(e)}
 
-        # what a leg costs WITHOUT the preheat: five timed steps right behind the idle gap of a fresh scene (the clock ramp included)
+        # what a leg costs WITHOUT the preheat: timed steps right behind the idle gap of a fresh scene, the clock ramp included -- and
+        # shown: the kernel time of every one of the first launches, which falls to the preheated figure as the part brings its clock up
         leg["name"] = "unpreheated"
         try:
             cold = {}
@@ -546,8 +548,14 @@ def main():
                 r0 = time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=5, preheat_ms=0.0,
                                ring=False if args.no_ring else None)
                 cold[name] = {"ms_per_step": 1e3 * r0["elapsed_s"] / r0["steps"], "kernel_ms": r0["kernel_ms"]}
+                time.sleep(0.2)
+                ramp = time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=24 if mode == nb.NB_MODE_FAST else 12, warmup=0,
+                                 preheat_ms=0.0, ring=False if args.no_ring else None)
+                cold[name]["kernel_ms_by_launch_from_idle"] = [round(x, 4) for x in ramp["kernel_ms_each"]]
             line["unpreheated"] = {"what": f"the same legs with --preheat-ms 0: {args.warmup} warm-up + 5 timed steps behind the idle gap a fresh "
-                                           "scene leaves (the part ramps its clock for 30-40 ms after such a gap)", "steps": 5, **cold}
+                                           "scene leaves (the part ramps its clock for 30-40 ms after such a gap); kernel_ms_by_launch_from_idle: the "
+                                           "kernel time of each launch from the very first one after the gap (no warm-up) -- the same kernel, the "
+                                           "same work, a rising clock: the difference to the headline is the part's, not the code's", "steps": 5, **cold}
         except Exception as e:  # pragma: no cover
             line["unpreheated"] = {"error": repr(e)}
 

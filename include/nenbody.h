@@ -262,6 +262,8 @@ int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t fi
  *   then nb_launch_ring_finish as above.
  * One step, with `x` a second stream for the exchanges:
  *     OWN | wait(all-gather of the last step) | REST | [x: second exchange] SUMS | wait(x) | finish | [x: all-gather]
+ * (a host whose cross-stream waits are dear keeps the second exchange on the compute stream -- REST | SUMS | exchange | finish --
+ * as nb_shard_step does: two waits cost more than the 9 us of SUMS they would hide; the all-gather's two waits hide behind OWN)
  * Same arguments in every call of a step (same scratch, untouched between them: nb_ring_scratch_bytes() covers both forms).
  * The sums are added in another (fixed) order than nb_launch_ring_fold's: run-to-run identical, FAST's tolerances, its own bits.
  * nb_ring_phased: 1 where the shape can run its step this way (nb_ring_partners() > 0 and the rank's rows fit one launch -- every
@@ -354,7 +356,8 @@ int nb_shard_set_boids_split(nb_shard *sh, int on);
  * does not need them.  A shard in the ordered fold folds its own slot of the snapshot while the all-gather of the other slots is
  * still in flight, waits for it, then folds the rest (the two phases of nb_launch_step_phase).  A shard in the pairs form
  * (nb_shard_pairs_partners() > 0, nb_ring_phased()) runs the phases of nb_launch_ring_fold_phase: pairs inside its own slot while
- * the all-gather lands, every other pair, then the second exchange beside the reduce of its own sums (round 5).  The order of the
+ * the all-gather lands on the second stream, every other pair, the sums, the second exchange (on the shard's own stream), finish
+ * (round 5).  The order of the
  * additions changes, which FAST may and STRICT may not: a STRICT shard (and a world of one) ignores the request and stays
  * kernel -> exchange in sequence.  Host-supplied exchanges (nb_shard_use_gather / nb_shard_use_ring) receive the second stream
  * and must order their work on it. */

@@ -2390,7 +2390,8 @@ int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_
     if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
     if (!dbg.ring.or_else((uint64_t)n_total * count >= kRingMinPairs ? 1u : 0u)) return NB_OK;
     out->partners = nbk::ring_partners(n_total, first, count, out->np);
-    out->phased = out->partners != 0u && nbk::ring_phased(n_total, first, count, out->np, out->ga, out->wpb);
+    // (the phases' shape is searched for ONCE, here: c4_own / c4_rest / cap leave resolved, and every launch of the plan names them)
+    out->phased = out->partners != 0u && nbk::ring_phased(n_total, first, count, out->np, out->ga, out->wpb, &out->c4_own, &out->c4_rest, &out->cap);
     return NB_OK;
 }
 size_t ring_scratch_bytes(const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count)

@@ -110,7 +110,8 @@ size_t ring_scratch_floats(uint32_t n_total, uint32_t first, uint32_t count, uin
 // the step in PHASES (round 5): can this shape run them (one launch covers the rank)?  what: 1 the pairs inside the rank's own slot
 // that one round of workgroups holds, 2 every other pair + the sums of the ranks in front, 3 the rank's own sums; c4_*: sub-tiles
 // per workgroup of a phase, cap: sub-tiles of a block's own part that phase 1 takes (0: defaults)
-bool ring_phased(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb);
+bool ring_phased(uint32_t n_total, uint32_t first, uint32_t count, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t *c4_own = nullptr, uint32_t *c4_rest = nullptr,
+                 uint32_t *cap = nullptr);  // the three come back resolved (0 in: choose): a launch that names them skips the search
 hipError_t launch_fast_ring_phase(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap, uint32_t what,
                                   void *scratch, float4 *sums, hipStream_t s);
 hipError_t launch_ring_phase_kernels(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap, uint32_t what,

@@ -9,7 +9,7 @@
 #                               profiles/hbm_traffic.json)
 # The program after `--` is python3 itself (no env / bash -c hop: the profiler has initialised the GPU by then).
 set -u
-OUT=${1:-gpurun_out/prof_r04}
+OUT=${1:-gpurun_out/prof_r05}
 ROOT=$(pwd)
 mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
