@@ -2366,6 +2366,7 @@ struct RingPlan {
     uint32_t partners;  // 0: this shape does not take the form
     uint32_t c4_own, c4_rest, cap;  // the step in phases: sub-tiles per workgroup, sub-tiles of a block's own part in the first phase (0: the kernels' defaults)
     bool phased;        // the shape can run its step in phases (nb_launch_ring_fold_phase)
+    size_t scratch_floats;  // rows behind the planes area: the most ANY rank of the job needs (a host may size one buffer for all)
 };
 // Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and enough pairs per rank that what
 // the form saves pays for its second exchange: against the ordered fold of the same shard it saves n_total x count / 3e7 us
@@ -2387,16 +2388,22 @@ int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_
     out->c4_rest = dbg.ring_c4_rest.or_else(0u);
     out->cap = dbg.ring_cap.or_else(0u);
     out->phased = false;
+    out->scratch_floats = 0;
     if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
     if (!dbg.ring.or_else((uint64_t)n_total * count >= kRingMinPairs ? 1u : 0u)) return NB_OK;
     out->partners = nbk::ring_partners(n_total, first, count, out->np);
+    // the rows: the phases' layout differs a little from rank to rank (the lists of the upper half of the ring are a block shorter), so
+    // the size is the largest of all ranks' -- every rank of a job gets the same answer, as before the phases existed
+    if (out->partners)
+        for (uint32_t f = 0; (uint64_t)f + count <= n_total; f += count)
+            out->scratch_floats = std::max(out->scratch_floats, nbk::ring_scratch_floats(n_total, f, count, out->np, out->ga, out->wpb, out->c4_own, out->c4_rest, out->cap));
     // (the phases' shape is searched for ONCE, here: c4_own / c4_rest / cap leave resolved, and every launch of the plan names them)
     out->phased = out->partners != 0u && nbk::ring_phased(n_total, first, count, out->np, out->ga, out->wpb, &out->c4_own, &out->c4_rest, &out->cap);
     return NB_OK;
 }
 size_t ring_scratch_bytes(const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count)
 {
-    return nbk::strict_bc_scratch_bytes(n_total) + nbk::ring_scratch_floats(n_total, first, count, rp.np, rp.ga, rp.wpb, rp.c4_own, rp.c4_rest, rp.cap) * sizeof(float);
+    return nbk::strict_bc_scratch_bytes(n_total) + rp.scratch_floats * sizeof(float);
 }
 int cached_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, const RingPlan **out, std::string *err)
 {
