@@ -153,6 +153,30 @@ public:
     void step_boids(uint32_t k = 1, const nb_boids_params *params = nullptr) { check_sh(nb_shard_step_boids(sh_, k, params)); }
     // FAST only (a STRICT shard ignores it): fold the rank's own slot while the exchange of the others is in flight
     void set_overlap(bool on) { check_sh(nb_shard_set_overlap(sh_, on ? 1 : 0)); }
+    // both exchanges once on a known pattern, checked on every rank, with fallbacks (collective).  gather: 0 in place, 1 from a copy;
+    // ring: -1 no pairs form, 0 one group, 1 one group per distance, 2 dropped for the ordered fold
+    struct ExchangePaths {
+        int gather, ring;
+    };
+    ExchangePaths verify_exchanges()
+    {
+        ExchangePaths p{0, -1};
+        check_sh(nb_shard_verify_exchanges(sh_, &p.gather, &p.ring));
+        return p;
+    }
+    // every form a FAST step can take timed on this machine (slowest rank; collective), the fastest kept, the state put back:
+    // 0 the ordered fold, 1 the pairs form, 2 the pairs form in phases; ms_per_step[form] < 0: not offered
+    struct FormChoice {
+        int chosen;
+        double ms_per_step[3];
+    };
+    FormChoice choose_form(uint32_t steps = 4)
+    {
+        FormChoice c{};
+        check_sh(nb_shard_choose_form(sh_, steps, &c.chosen, c.ms_per_step));
+        return c;
+    }
+    void set_pairs(bool on) { check_sh(nb_shard_set_pairs(sh_, on ? 1 : 0)); }  // name the form (run-to-run identical FAST bits)
     // waits; throws Error(NB_ERR_STATE) if a kernel of this shard reported a failure (a block-chain wave gave up waiting)
     void sync() { check_sh(nb_shard_sync(sh_)); }
     // all n positions (the replica); this rank's velocities and model matrices

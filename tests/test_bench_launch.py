@@ -115,6 +115,24 @@ def test_gpus_4_mode_fast_rehearsal_chooses_its_form_by_timing_and_runs_the_phas
     assert line["parity_check"]["within_tolerance"] is True and line["comm"]["fast_form"] is None
 
 
+@pytest.mark.gpu
+def test_gpus_5_strict_ragged_rehearsal_proves_its_parity():
+    """`bench.py --gpus 5` over gloo on the one card (five ranks + this process: the pool's process guard allows six on a card): a
+    world that does not divide 131 072 -- slots of 26 215 bodies, the last rank short --, every rank in the block chain, the in-place
+    all-gather verified on a pattern first, and the line's own parity check: after preheat + warm-up + timed steps every bit of the
+    state is the CPU oracle's at that step (STRICT does not depend on the world)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "5", "--steps", "3", "--warmup", "1", "--preheat-ms", "30", "--no-cpu-baseline", "--no-secondary"],
+                       env=_env(NB_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 5 and "x5" in line["config"]["sharding"] and line["config"]["mode"] == "strict"
+    pc = line["parity_check"]
+    assert pc["bits_equal"] is True and pc["k"] == line["preheat"]["steps"] + 1 + 3
+    assert line["comm"]["world"] == 5 and line["comm"]["distinct_devices"] == 1 and len(line["comm"]["device_uuids"]) == 5
+    assert line["comm"]["exchange_paths"] == {"world": 5, "all_gather": "in_place", "ring_exchange": None, "verified": True}
+    assert line["roofline"]["kernel"] == "step_strict_bc_kernel"
+
+
 def _preheat_rank(rank, world, port, out_dir):
     import time
 

@@ -194,3 +194,55 @@ def test_fast_pairs_form_on_shards_random_problems(nb, oracle, monkeypatch, case
     acc = np.abs(ref_v - vel).max()
     assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, what
     assert np.abs(got_p - ref_p).max() <= 2e-5 * acc + 1.6e-5, what
+
+
+@pytest.mark.parametrize("case", range(max(12, CASES // 2)))
+def test_fast_pairs_form_in_phases_random_problems(nb, oracle, monkeypatch, case):
+    """the same form with its step in PHASES (nb_launch_ring_fold_phase: pairs inside a rank's own slot apart from all others, the
+    first phase given a snapshot whose other slots are NaN) over random rank counts, blocks per rank, bodies per lane, sub-tiles per
+    workgroup of both phases and caps of the first (none of it, a part, all of a block's own part), planar / 3-D / partly planar data
+    -- planar own slots inside a 3-D set and the other way round --, other constants: within FAST's tolerance of the oracle and of
+    the one-launch form, identical bits from run to run"""
+    from test_gpu_ring import ring_steps_on_one_gpu
+
+    rng = np.random.default_rng(12000 + case)
+    np_ = int(rng.choice([2, 4]))
+    world = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 16]))
+    nb_per_rank = int(rng.integers(1, 7 if np_ == 4 else 10))
+    n = 128 * np_ * nb_per_rank * world
+    monkeypatch.setenv("NB_RING", "1")
+    monkeypatch.setenv("NB_RING_NP", str(np_))
+    if case % 3 != 0:
+        monkeypatch.setenv("NB_RING_C4_OWN", str(int(rng.integers(1, 12))))
+    if case % 3 == 1:
+        monkeypatch.setenv("NB_RING_C4_REST", str(int(rng.integers(1, 40))))
+    if case % 4 != 3:
+        monkeypatch.setenv("NB_RING_CAP", str(int(rng.choice([1, 2, 4, 7, 8, 16, 24, 100000]))))
+    if case % 5 == 4:
+        monkeypatch.setenv("NB_FAST_NO_SHARE", "1")
+    p = nb.default_params(mode=nb.NB_MODE_FAST)
+    p.dt = float(rng.choice([0.1, 0.01]))
+    p.G = float(rng.choice([0.001, 1.0, -0.05]))
+    p.bias = float(rng.choice([1e-7, 1e-3, 2.0]))
+    pos = (rng.uniform(-100, 100, (n, 3))).astype(np.float32)
+    vel = (rng.uniform(0, 0.1, (n, 3))).astype(np.float32)
+    S = n // world
+    if case % 2 == 0:
+        pos[:, 2] = 0
+        vel[:, 2] = 0
+        if case % 4 == 2:            # one rank's slot 3-D inside a planar set: its own-slot phase alone takes the 3-D path
+            r = int(rng.integers(0, world))
+            pos[r * S:(r + 1) * S, 2] = rng.uniform(-100, 100, S).astype(np.float32)
+    elif case % 4 == 1:
+        pos[: n // 2, 2] = 0         # planar own slots inside a 3-D set: the second phase sweeps them on the 3-D path
+    what = f"case {case}: n={n} world={world} np={np_} blocks/rank={nb_per_rank} G={p.G} bias={p.bias}"
+    got_p, got_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1, phases=True)
+    again_p, again_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1, phases=True)
+    assert (bits(got_p) == bits(again_p)).all() and (bits(got_v) == bits(again_v)).all(), what + ": not deterministic"
+    ref_p, ref_v = oracle.run(pos, vel, 1, np.float32(p.dt), np.float32(p.G), np.float32(p.bias))
+    acc = np.abs(ref_v - vel).max()
+    assert np.isfinite(got_v).all(), what + ": a slot in flight was read"
+    assert np.abs(got_v - ref_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, what
+    assert np.abs(got_p - ref_p).max() <= 2e-5 * acc + 1.6e-5, what
+    one_p, one_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1)
+    assert np.abs(got_v - one_v).max() <= 2e-5 * acc + 1.2e-7 * np.abs(ref_v).max() + 1e-9, what + ": against the one-launch form"
