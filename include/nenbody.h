@@ -312,6 +312,36 @@ int nb_launch_status(void *stream);
 int nb_launch_pack(uint32_t count, const void *xyz, void *rec4, void *stream);
 int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void *stream);
 
+/* -- the exchanges of a multi-GPU step as PULLS over xGMI (round 5) ---------------------------------------- *
+ * No collective library, no second stream, no kernel that polls: every rank registers a few device buffers (the two position
+ * replicas, the pairs form's `sums`) and hands the others a blob of IPC memory handles (nb_peers_export; the host moves the blobs:
+ * MPI, torch.distributed, a file); after nb_peers_import every rank holds mappings of every other rank's buffers and of a block of
+ * flag words.  An exchange is then, on the rank's OWN stream:
+ *     nb_peers_signal   hipStreamWriteValue32(my flag[channel] = next count): "what I launched so far is complete"
+ *     ... whatever needs no other rank (the pairs inside the rank's own slot: nb_launch_ring_fold_phase(NB_RING_OWN)) ...
+ *     nb_peers_gather   hipStreamWaitValue32(peer's flag[channel] >= count) for every peer, then ONE kernel copies slot q of peer q's
+ *                       buffer into slot q of this rank's (16-byte loads over xGMI)
+ *     nb_peers_ring     the same for the pairs form's second exchange: chunk d of rank (r - d)'s buffer -> chunk d - 1 of `recv`
+ * Nobody writes another rank's memory, and a kernel reads a peer's memory only behind that peer's signal.  Buffers may be pieces of
+ * larger allocations (a caching allocator's).  Up to 16 ranks (one xGMI domain), all in processes of one node.  Ranks call the
+ * same sequence of signals and exchanges per channel (SPMD).  That a buffer is not rewritten while a peer still pulls from it is the
+ * CALLER's ordering: alternate the two position replicas (as every host here does) and rewrite `sums` only behind a gather.
+ * nb_shard_use_peers / ShardedScene(exchange="peers") wire this into a step.  Measured between two processes on one GPU: a signal +
+ * wait + 256 KB pull round trip in ~10 us (profiles/r05/ubench_ipc.log); between GPUs: not run in this build -- verify_exchanges
+ * checks a pattern through it before the first step, and falls back. */
+#define NB_PEERS_MAX_BUFFERS 4
+#define NB_PEERS_CHANNELS 4
+typedef struct nb_peers nb_peers;
+size_t nb_peers_blob_bytes(void);
+int nb_peers_create(int rank, int world, nb_peers **out);
+void nb_peers_destroy(nb_peers *p);
+const char *nb_peers_last_error(const nb_peers *p);
+int nb_peers_export(nb_peers *p, void *const *bufs, const size_t *bytes, int nbufs, void *blob);
+int nb_peers_import(nb_peers *p, const void *blobs /* world x nb_peers_blob_bytes(), rank-major */);
+int nb_peers_signal(nb_peers *p, int channel, void *stream);
+int nb_peers_gather(nb_peers *p, int channel, int buf, size_t slot_bytes, void *stream);
+int nb_peers_ring(nb_peers *p, int channel, int buf, void *recv, size_t chunk_bytes, int partners, void *stream);
+
 /* -- sharded scene: one process (or thread) per GPU ------------------------------------------------------ *
  * The host side of the multi-GPU path in the library itself, for hosts that do not bring torch: rank r of `world`
  * owns bodies [r*slot, r*slot + count) with slot = ceil(n / world) (trailing ranks may be short or empty) and a replica
@@ -344,6 +374,17 @@ int nb_shard_use_gather(nb_shard *sh, nb_gather_fn fn, void *user);
  * chunk_bytes, chunk d - 1 for rank (rank + d) % world; `recv`: chunk d - 1 from rank (rank - d) % world; both device memory,
  * `send` ready on `stream`, `recv` must be complete or ordered on `stream` on return.  nb_shard_set_pairs(sh, 0) keeps the
  * ordered fold whatever the shape; nb_shard_pairs_partners: the D a step will use (0: the ordered fold). */
+/* Both exchanges as PULLS over xGMI (nb_peers_* above; round 5): nb_shard_peer_export fills this rank's blob of nb_peers_blob_bytes()
+ * bytes, the host hands every rank ALL blobs, rank-major (any channel), nb_shard_peer_import maps the others' position replicas and
+ * `sums`.  From then on the all-gather and the pairs form's second exchange are a signal, stream waits on the peers' flag words and
+ * one copy kernel, all on the shard's own stream; with nb_shard_set_overlap the signal goes out behind the finish kernel and the waits
+ * come behind the next step's own-slot pairs -- no second stream, no idle gap.  No RCCL communicator is needed (one may exist beside it:
+ * the boids controller, which moves another buffer, uses the exchange chosen before).  All ranks in processes of ONE node, at most 16.
+ * nb_shard_use_peers(sh, 0 / 1) switches between this and the exchange chosen before.  Collective in effect: every rank imports
+ * before any rank steps.  nb_shard_verify_exchanges checks it on a pattern like any other exchange. */
+int nb_shard_peer_export(nb_shard *sh, void *blob);
+int nb_shard_peer_import(nb_shard *sh, const void *blobs);
+int nb_shard_use_peers(nb_shard *sh, int on);
 typedef int (*nb_ring_fn)(void *user, const void *send, void *recv, size_t chunk_bytes, int partners, int rank, int world, void *stream);
 int nb_shard_use_ring(nb_shard *sh, nb_ring_fn fn, void *user);
 int nb_shard_set_pairs(nb_shard *sh, int on);

@@ -138,6 +138,18 @@ PROTOTYPES = {
     "nb_shard_pairs_partners": (c_int, [c_void_p]),
     "nb_shard_pairs_overlapped": (c_int, [c_void_p]),
     "nb_shard_verify_exchanges": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "nb_shard_peer_export": (c_int, [c_void_p, c_void_p]),
+    "nb_shard_peer_import": (c_int, [c_void_p, c_void_p]),
+    "nb_shard_use_peers": (c_int, [c_void_p, c_int]),
+    "nb_peers_blob_bytes": (c_size_t, []),
+    "nb_peers_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    "nb_peers_destroy": (None, [c_void_p]),
+    "nb_peers_last_error": (c_char_p, [c_void_p]),
+    "nb_peers_export": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_int, c_void_p]),
+    "nb_peers_import": (c_int, [c_void_p, c_void_p]),
+    "nb_peers_signal": (c_int, [c_void_p, c_int, c_void_p]),
+    "nb_peers_gather": (c_int, [c_void_p, c_int, c_int, c_size_t, c_void_p]),
+    "nb_peers_ring": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "nb_shard_choose_form": (c_int, [c_void_p, c_uint32, POINTER(c_int), POINTER(ctypes.c_double)]),
     "nb_shard_set_boids_split": (c_int, [c_void_p, c_int]),
     "nb_shard_range": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32)]),

@@ -2841,4 +2841,5 @@ NB_EXPORT int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void
     NB_LAUNCH_TLS(nbk::launch_unpack(count, (const float4 *)rec4, (float *)xyz, (hipStream_t)stream));
 }
 
+#include "nb_peers.inc"
 #include "nb_shard.inc"

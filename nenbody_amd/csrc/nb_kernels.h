@@ -147,6 +147,14 @@ hipError_t launch_unstage(uint32_t slot, uint32_t world, const float4 *stage, fl
 // check adds the number of records that differ to *mismatches
 hipError_t launch_exchange_pattern(float4 *dst, uint32_t count, float rank, float salt, bool fill_nan, hipStream_t s);
 hipError_t launch_exchange_check(const float4 *src, uint32_t count, float rank, float salt, uint32_t *mismatches, hipStream_t s);
+// the exchanges as pulls (nb_peers.inc): `copies` copies of `records` 16-byte records each, src[k] (another rank's memory) -> dst[k]
+constexpr int kPeerMax = 16;   // ranks of one xGMI domain
+struct PullArgs {
+    const float4 *src[kPeerMax];
+    float4 *dst[kPeerMax];
+    uint32_t copies, records;
+};
+hipError_t launch_peer_pull(const PullArgs &a, hipStream_t s);
 hipError_t launch_pack(uint32_t count, const float *xyz, float4 *rec, hipStream_t s);
 hipError_t launch_unpack(uint32_t count, const float4 *rec, float *xyz, hipStream_t s);
 // both stride-3 arrays -> records, and matrices + both record arrays -> stride-3 (null outputs skipped), one launch each

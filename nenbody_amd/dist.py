@@ -551,7 +551,7 @@ class NativeShard:
 
     The same decomposition as :class:`ShardedScene` -- index ranges, one exchange of positions per step (velocities too
     for the boids controller) -- without torch: the exchange is RCCL (``comm_id`` = the bytes of :func:`comm_id`, made
-    on one rank) or ``gather``, a callable ``(buf_ptr, slot_bytes, rank, world, stream_ptr) -> None`` that completes the
+    on one rank), pulls over xGMI (``peers``: a collective callable blob -> all ranks' blobs; round 5) or ``gather``, a callable ``(buf_ptr, slot_bytes, rank, world, stream_ptr) -> None`` that completes the
     all-gather of the device buffer at ``buf_ptr``.  FAST with equal ranks of whole blocks takes the pairs form (every unordered
     pair once, ``nb_launch_ring_fold``) where its second exchange exists: RCCL's send / receive, or ``ring``, a callable
     ``(send_ptr, recv_ptr, chunk_bytes, partners, rank, world, stream_ptr) -> None`` beside ``gather`` (chunk d - 1 of ``send``
@@ -562,7 +562,7 @@ class NativeShard:
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, rank: int = 0, world: int = 1,
                  comm_id: Optional[bytes] = None, gather=None, overlap: bool = False, ring=None, pairs: Optional[bool] = None,
-                 boids_split: bool = False):
+                 boids_split: bool = False, peers=None):
         lib = _lib.load()
         pos = np.ascontiguousarray(positions, dtype=np.float32)
         vel = np.ascontiguousarray(velocities, dtype=np.float32)
@@ -609,6 +609,15 @@ class NativeShard:
 
                 self._ring_keepalive = _lib.RING_FN(ring_trampoline)
                 self._check(lib.nb_shard_use_ring(self._sh, self._ring_keepalive, None))
+            if peers is not None:
+                # both exchanges as pulls over xGMI (nb_shard_peer_export / _import): `peers` is a collective callable that takes this
+                # rank's blob (bytes) and returns every rank's, rank-major, concatenated -- any channel the host has
+                blob = ctypes.create_string_buffer(int(lib.nb_peers_blob_bytes()))
+                self._check(lib.nb_shard_peer_export(self._sh, blob))
+                every = peers(blob.raw)
+                if len(every) != self.world * len(blob.raw):
+                    raise ValueError("peers(blob) must return world blobs, rank-major, concatenated")
+                self._check(lib.nb_shard_peer_import(self._sh, ctypes.create_string_buffer(every, len(every))))
             if pairs is not None:
                 self._check(lib.nb_shard_set_pairs(self._sh, 1 if pairs else 0))
             if boids_split:  # the boids step's j range in slices: the reference's neighbour sets and counts, reassociated sums
@@ -633,6 +642,10 @@ class NativeShard:
     def pairs_overlapped(self) -> bool:
         """does a step take the pairs form in phases, both exchanges on a second stream (``nb_shard_pairs_overlapped``)?"""
         return int(self._lib.nb_shard_pairs_overlapped(self._sh)) == 1
+
+    def use_peers(self, on: bool) -> None:
+        """switch between the pulls over xGMI (after ``peers=`` at construction) and the exchange chosen before"""
+        self._check(self._lib.nb_shard_use_peers(self._sh, 1 if on else 0))
 
     def verify_exchanges(self):
         """both exchanges once on a known pattern, checked on every rank (``nb_shard_verify_exchanges``; collective): returns

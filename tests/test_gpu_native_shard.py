@@ -150,7 +150,7 @@ def _hip_runtime():
 
 
 def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=None, with_ring=False, seed=None, force_pairs=False,
-                 verify=None):
+                 verify=None, peers=False):
     import sys
 
     from conftest import ROOT
@@ -203,11 +203,20 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
             assert hip.hipMemcpy(recv, got.data_ptr(), partners * chunk_bytes, 1) == 0
             ring_calls.append(partners)
 
+        def swap_blobs(blob):   # the handles of every rank's buffers, through the host's own channel (here: gloo)
+            every = [None] * world
+            dist.all_gather_object(every, blob)
+            return b"".join(every)
+
         pos, vel = state3d(oracle, n, seed=n) if seed is None else oracle.init_state(n, seed)
         with nenbody_amd.NativeShard(pos, vel, nenbody_amd.default_params(mode=mode), rank=rank, world=world,
-                                     gather=gather, overlap=overlap, ring=ring if with_ring else None) as sh:
+                                     gather=None if peers == "only" else gather, overlap=overlap, ring=ring if (with_ring and peers != "only") else None,
+                                     peers=swap_blobs if peers else None) as sh:
             extra = {}
-            if verify:   # both exchanges on a known pattern first, then the machine is asked which form to take
+            if verify == "verify_only":   # the pattern through whatever exchange the shard uses; the form stays the one asked for
+                assert sh.verify_exchanges() == (0, 0 if sh.partners else -1)
+                assert sh.pairs_overlapped == bool(overlap and sh.partners)
+            elif verify:   # both exchanges on a known pattern first, then the machine is asked which form to take
                 before = sh.partners
                 paths = sh.verify_exchanges()
                 assert paths == ((0, 2) if verify == "lossy_ring" else (0, 0 if before else -1)), paths
@@ -347,6 +356,43 @@ def test_native_shard_verifies_its_exchanges_and_asks_the_machine_for_the_form(t
         assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r} velocities"
         assert int(got["ring_calls"]) == (2 if int(got["partners"]) else 0)
     assert len(chosen) == 1     # every rank took the same form
+
+
+@pytest.mark.parametrize("world,n,mode_name,overlap", [(2, 3000, "strict", False), (3, 1001, "strict", False), (4, 32768, "fast", False),
+                                                       (4, 32768, "fast", True), (2, 32768, "fast", True), (3, 49152, "fast", True)])
+def test_shards_that_pull_their_exchanges_over_ipc(tmp_path, nb, oracle, world, n, mode_name, overlap):
+    """nb_shard_peer_export / _import (round 5): NO collective library and no host exchange function -- every rank maps the others'
+    position replicas and `sums` through IPC memory handles (swapped here over gloo), and an exchange is a signal in the rank's own
+    memory, stream waits on the peers' flag words and one copy kernel on the shard's own stream.  The ranks are PROCESSES sharing the
+    one GPU: the protocol (who waits for whom, which buffer is pulled when, that nothing is overwritten under a peer's pull) is what
+    is tested; that a peer's stores are visible when its flag says so is a property of two GPUs, which verify_exchanges checks where
+    it first meets them.  STRICT: ragged worlds, bit-identical to the oracle; FAST: the pairs form, its second exchange pulled too --
+    in sequence and in phases (the signal behind the finish, the pull behind the next step's own-slot pairs) -- at FAST's tolerance."""
+    import torch.multiprocessing as mp
+
+    strict = mode_name == "strict"
+    schedule = (("nbody", 3), ("nbody", 2))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_STRICT if strict else nb.NB_MODE_FAST, str(tmp_path), overlap, schedule, not strict, 77,
+                                 not strict, "verify_only", "only"), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, 77)
+    p_ref, v_ref = reference(oracle, pos, vel, schedule)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        first, count = int(got["first"]), int(got["count"])
+        assert (first, count) == nb.partition(n, world)[r]
+        assert int(got["calls"]) == 0 and int(got["ring_calls"]) == 0          # no host exchange ran
+        if strict:
+            assert_bits_equal(got["pos"], p_ref, f"rank {r} positions (replica)")
+            assert_bits_equal(got["vel"], v_ref[first:first + count], f"rank {r} velocities")
+        else:
+            scale = float(np.abs(v_ref - vel).max())
+            dv = np.abs(got["vel"] - v_ref[first:first + count]).max(axis=1)
+            assert np.quantile(dv, 0.999) <= 2e-4 * scale and dv.max() <= 2e-2 * scale, f"rank {r}: {np.quantile(dv, 0.999) / scale:.2e} {dv.max() / scale:.2e}"
+            dp = np.abs(got["pos"] - p_ref).max(axis=1)
+            assert np.quantile(dp, 0.999) <= 4e-4 * scale and dp.max() <= 4e-2 * scale, f"rank {r} positions (replica)"
 
 
 def test_native_shard_boids_split_form(nb, oracle):
