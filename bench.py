@@ -190,7 +190,7 @@ def preheat(step, torch, dist, world, dev, ms):
 
 
 def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, warmup=None, overlap=False, ring=None, preheat_ms=None,
-              ring_overlap=None, choose=False, parity=False):
+              ring_overlap=None, choose=False, parity=False, exchange_kind=None):
     """ring: None = the library's plan (FAST on equal ranks of a multi-GPU job: every unordered pair once, two exchanges per
     step), False = the ordered fold with its one exchange.  ring_overlap: the pairs form in phases, its exchanges behind compute.
     choose: FAST at world > 1 -- let ShardedScene.choose_form time every form this shape can take and keep the fastest (the
@@ -211,6 +211,28 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     # untimed: bring the communicator and its channels up even when --warmup 0, and VERIFY both exchanges on a known pattern before
     # any step relies on them (a mismatch moves the exchange to its fallback; `exchange_paths` in the line says which path ran)
     exchange_paths = sc.verify_exchanges() if world > 1 else None
+    exchange = None
+    if world > 1 and exchange_kind is not None:   # an informational leg: the headline's choice, not another round of timing
+        if exchange_kind == "peers" and sc.setup_peers():
+            sc.exchange = "peers"
+        exchange = {"chosen": sc.exchange, "requested": exchange_kind}
+    elif world > 1 and args.exchange != "collective":
+        # the same exchanges as pulls over xGMI (IPC-mapped buffers, stream value waits, one copy kernel): mapped, verified on the
+        # pattern and TIMED against the collectives on this machine; the faster runs (--exchange peers: required, not timed)
+        if args.exchange == "peers":
+            ok = sc.setup_peers()
+            if ok:
+                sc.exchange = "peers"
+                exchange_paths = sc.verify_exchanges()
+            exchange = {"chosen": sc.exchange, "requested": "peers", "mapped": ok, "why": sc.peers_error}
+        else:
+            chosen = sc.choose_exchange(steps=6, warm=2)
+            exchange = {"chosen": chosen, "requested": "auto", "mapped": sc._peers is not None, "why": sc.peers_error,
+                        "ms_per_step": None if sc.exchange_times is None else {k_: (None if v_ is None else 1e3 * v_) for k_, v_ in sc.exchange_times.items()},
+                        "what": "ShardedScene.choose_exchange: RCCL's collectives against pulls over xGMI ordered by stream value waits "
+                                "(nb_peers_*), each verified on a pattern, 6 steps of this form each, slowest rank"}
+            if sc.exchange_report is not None:
+                exchange_paths = sc.exchange_report
     form = None
     if choose and world > 1 and sc.partners:
         pre0 = preheat(sc.step, torch, dist, world, dev, args.preheat_ms if preheat_ms is None else preheat_ms)
@@ -262,7 +284,7 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     each = [sum(a.elapsed_time(b) for a, b in ev[i * per_step:(i + 1) * per_step]) for i in range(steps)] if sc.count and used[0] == len(ev) else []
     out = {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "kernel_ms_each": each, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,
            "kernels": kernels, "mode": "fast" if mode == nb.NB_MODE_FAST else "strict", "partners": sc.partners, "world": world,
-           "ring_overlap": bool(sc.ring_overlap), "exchange_paths": exchange_paths, "form": form}
+           "ring_overlap": bool(sc.ring_overlap), "exchange_paths": exchange_paths, "form": form, "exchange": exchange}
     if parity:
         import numpy as np
 
@@ -285,6 +307,7 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
                                               "FAST is the same law reassociated: the worst body (a neighbour at r ~ 1e-4) is held to 1e-3 of the "
                                               "largest velocity change, as tests/test_gpu_ring.py holds it"}
             a.sync(); b.sync()
+    sc.close()   # (the mappings of the other ranks' buffers, where the exchange is pulls)
     return out
 
 
@@ -306,6 +329,10 @@ def main():
     ap.add_argument("--fast-form", choices=["auto", "pairs", "pairs_overlapped", "ordered"], default="auto",
                     help="multi-GPU --mode fast: the form a step takes -- auto (default): ShardedScene.choose_form times every form this "
                          "shape can take on this machine and the timed region runs the fastest; or name one (ordered == --no-ring)")
+    ap.add_argument("--exchange", choices=["auto", "collective", "peers"], default="auto",
+                    help="multi-GPU: how the ranks exchange -- collective: RCCL's all-gather (and grouped send / receive) through "
+                         "torch.distributed; peers: pulls over xGMI ordered by stream value waits (nb_peers_*: IPC-mapped buffers, no "
+                         "collective kernel); auto (default): both are verified on a pattern and timed on this machine, the faster runs")
     ap.add_argument("--overlap-leg", action="store_true",
                     help="multi-GPU only: also time FAST with the exchange overlapped (ShardedScene(overlap=True)); off by default "
                          "so that nothing untried on hardware can cost the scaling run its exit code")
@@ -386,6 +413,8 @@ def main():
     res = time_mode(nb, torch, dist, args, primary, rank, world, pos, vel, ring=False if args.no_ring else None, ring_overlap=named,
                     choose=primary == nb.NB_MODE_FAST and not args.no_ring and args.fast_form == "auto", parity=True)
 
+    headline_exchange = (res["exchange"] or {}).get("chosen", "collective") if world > 1 else None
+
     def summarise(r, data="planar"):
         steps_per_s = r["steps"] / r["elapsed_s"]
         kernel_s = r["kernel_ms"] * 1e-3
@@ -449,7 +478,7 @@ def main():
         "interactions_per_s": s["interactions_per_s"],
         "roofline": s["roofline"],
         "parity_check": res.get("parity_check"),
-        "comm": dict(comm, exchange_paths=res["exchange_paths"], fast_form=res["form"]),
+        "comm": dict(comm, exchange_paths=res["exchange_paths"], fast_form=res["form"], exchange=res["exchange"]),
         # BASELINE.json's north_star asks for >= 40 % of the fp32 roofline AND |dr| < 1e-4 against the reference after 1 000
         # steps.  The system is chaotic: only arithmetic identical to the reference's holds the second
         # line, and an exact binary32 divide costs 4 vector ops where the flop count says 1, which caps STRICT near 1/3.
@@ -483,7 +512,7 @@ def main():
         leg["name"] = "other_mode"
         try:
             # (multi-GPU: FAST as the ordered fold with its one exchange here; the pairs form on shards is a leg of its own below)
-            o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel, ring=False))
+            o = summarise(time_mode(nb, torch, dist, args, other_mode, rank, world, pos, vel, ring=False, exchange_kind=headline_exchange))
             line["other_mode"] = {"mode": "fast" if primary == nb.NB_MODE_STRICT else "strict",
                                   "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"]}
         except Exception as e:  # pragma: no cover
@@ -492,7 +521,7 @@ def main():
         if world > 1 and not (primary == nb.NB_MODE_FAST and res["partners"] and not res["ring_overlap"]):
             leg["name"] = "fast_pairs_on_shards"
             try:
-                r2 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=False)
+                r2 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=False, exchange_kind=headline_exchange)
                 if r2["partners"]:
                     o = summarise(r2)
                     line["fast_pairs_on_shards"] = {"what": "FAST, every unordered pair evaluated once across the ranks: a rank folds its bodies "
@@ -511,7 +540,7 @@ def main():
                 can = bool(probe.partners) and probe.backend.ring_phased(probe.params, probe.n, probe.first, probe.count)
                 del probe
                 if can:
-                    r3 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=True)
+                    r3 = time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, ring_overlap=True, exchange_kind=headline_exchange)
                     o = summarise(r3)
                     line["fast_pairs_on_shards_overlapped"] = {"what": "the pairs form on shards in phases: pairs inside the rank's own slot while the last "
                                                                        "step's all-gather lands, every other pair, the second exchange beside the reduce of the "
@@ -546,11 +575,11 @@ def main():
             for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
                 time.sleep(0.2)
                 r0 = time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=5, preheat_ms=0.0,
-                               ring=False if args.no_ring else None)
+                               ring=False if args.no_ring else None, exchange_kind=headline_exchange)
                 cold[name] = {"ms_per_step": 1e3 * r0["elapsed_s"] / r0["steps"], "kernel_ms": r0["kernel_ms"]}
                 time.sleep(0.2)
                 ramp = time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=24 if mode == nb.NB_MODE_FAST else 12, warmup=0,
-                                 preheat_ms=0.0, ring=False if args.no_ring else None)
+                                 preheat_ms=0.0, ring=False if args.no_ring else None, exchange_kind=headline_exchange)
                 cold[name]["kernel_ms_by_launch_from_idle"] = [round(x, 4) for x in ramp["kernel_ms_each"]]
             line["unpreheated"] = {"what": f"the same legs with --preheat-ms 0: {args.warmup} warm-up + 5 timed steps behind the idle gap a fresh "
                                            "scene leaves (the part ramps its clock for 30-40 ms after such a gap); kernel_ms_by_launch_from_idle: the "
@@ -562,7 +591,7 @@ def main():
         if args.overlap_leg and world > 1:
             leg["name"] = "fast_overlap"
             try:
-                o = summarise(time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, overlap=True))
+                o = summarise(time_mode(nb, torch, dist, args, nb.NB_MODE_FAST, rank, world, pos, vel, overlap=True, exchange_kind=headline_exchange))
                 line["fast_overlap"] = {"what": "FAST, each step folds the rank's own slot while the all-gather of the others is in "
                                                 "flight (nb_launch_step_phase), then the rest",
                                         "value": o["body_updates_per_s"], "ms_per_step": o["ms_per_step"]}
@@ -577,8 +606,8 @@ def main():
             nb.reload_env()
             f3 = {}
             for name, mode in (("strict", nb.NB_MODE_STRICT), ("fast", nb.NB_MODE_FAST)):
-                o = summarise(time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=max(3, min(args.steps, 10)), warmup=1),
-                              data="3d")
+                o = summarise(time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=max(3, min(args.steps, 10)), warmup=1,
+                                        exchange_kind=headline_exchange), data="3d")
                 f3[name] = {"ms_per_step": o["ms_per_step"], "value": o["body_updates_per_s"], "roofline_frac": o["roofline"]["frac"],
                             "executed_per_interaction": o["roofline"]["executed_per_interaction"]}
             line["force_3d"] = f3

@@ -153,7 +153,7 @@ class ShardedScene:
 
     def __init__(self, positions, velocities, params: Optional[NbParams] = None, *, device=None, group=None,
                  backend=None, rank: Optional[int] = None, world: Optional[int] = None, overlap: bool = False,
-                 ring: Optional[bool] = None, ring_overlap: Optional[bool] = None):
+                 ring: Optional[bool] = None, ring_overlap: Optional[bool] = None, exchange: str = "collective"):
         import torch
         import torch.distributed as dist
 
@@ -226,15 +226,107 @@ class ShardedScene:
         self.gather_in_place = True      # RCCL all-gather with this rank's slot of the receive buffer as the send buffer
         self.ring_grouped = True         # the second exchange as ONE group of sends and receives (else: one group per distance)
         self.exchange_report = None
+        # "collective": torch.distributed (RCCL over xGMI: all-gather, grouped send / receive); "peers": pulls over xGMI ordered by
+        # stream value waits (nb_peers_*, include/nenbody.h: no collective kernel, no second stream) for the position replicas and
+        # `sums` -- everything else (velocities on demand, the boids controller's staging buffer) stays collective
+        self.exchange = "collective"
+        self._peers = None
+        self._peers_sums = False
+        if exchange not in ("collective", "peers"):
+            raise ValueError('exchange must be "collective" or "peers"')
+        if exchange == "peers" and world > 1:
+            if not self.setup_peers():
+                raise _lib.NbError(_lib.NB_ERR_STATE, "exchange=\"peers\": the ranks could not map each other's buffers (" + str(self.peers_error) + ")")
+            self.exchange = "peers"
         self.velfull = None      # boids only: replicas of ALL velocities (ping-pong), built on first use
         self._pvstage = None     # boids, world > 1: [world][pos slot | vel slot], what the one all-gather per step moves
         self.velfull_valid = False
+
+    # -- the exchanges as pulls over xGMI (nb_peers_*) ----------------------------------------------------------------------------
+    def setup_peers(self) -> bool:
+        """Collective: every rank registers its two position replicas (and `sums`, where the pairs form is planned), the blobs of
+        IPC handles travel through torch.distributed, every rank maps the others'.  True when EVERY rank succeeded (one all-reduce);
+        on False nothing changed and ``peers_error`` says why on the ranks that failed."""
+        torch, dist = self.torch, self.dist
+        self.peers_error = None
+        if self._peers is not None:
+            return True
+        lib = self.backend.lib if hasattr(self.backend, "lib") else None
+        handle, ok = ctypes.c_void_p(), lib is not None and self.device.type == "cuda" and self.world <= 16
+        every = None
+        if not ok:
+            self.peers_error = "needs the HIP backend, device buffers and at most 16 ranks"
+        blob = ctypes.create_string_buffer(int(lib.nb_peers_blob_bytes())) if lib is not None else None
+        if ok:
+            with torch.cuda.device(self.device):
+                bufs = [self.pos[0], self.pos[1]] + ([self.sums] if self.sums is not None else [])
+                rc = lib.nb_peers_create(self.rank, self.world, ctypes.byref(handle))
+                if rc == _lib.NB_OK:
+                    ptrs = (ctypes.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+                    sizes = (ctypes.c_size_t * len(bufs))(*[b.numel() * b.element_size() for b in bufs])
+                    rc = lib.nb_peers_export(handle, ptrs, sizes, len(bufs), blob)
+                if rc != _lib.NB_OK:
+                    ok, self.peers_error = False, lib.nb_peers_last_error(handle if handle else None).decode()
+        # (every rank takes part in the exchange of blobs whether it succeeded or not: a collective must not be skipped by some)
+        every = [None] * self.world
+        dist.all_gather_object(every, blob.raw if ok else b"", group=self.group)
+        if ok and all(len(e) == len(blob.raw) for e in every):
+            joined = b"".join(every)
+            with torch.cuda.device(self.device):
+                rc = lib.nb_peers_import(handle, ctypes.create_string_buffer(joined, len(joined)))
+            if rc != _lib.NB_OK:
+                ok, self.peers_error = False, lib.nb_peers_last_error(handle).decode()
+        elif ok:
+            ok, self.peers_error = False, "another rank could not export its buffers"
+        on_device = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        if not bool(t.item()):
+            if handle:
+                lib.nb_peers_destroy(handle)
+            self.peers_error = self.peers_error or "another rank failed"
+            return False
+        self._peers, self._peers_sums = handle, self.sums is not None
+        return True
+
+    def _peers_call(self, rc) -> None:
+        if rc != _lib.NB_OK:
+            raise _lib.NbError(rc, self.backend.lib.nb_peers_last_error(self._peers).decode())
+
+    class _Pull:
+        """an exchange by pulls whose signal is out: ``wait()`` issues the stream waits on the peers' flag words and the copy kernel"""
+
+        def __init__(self, issue):
+            self._issue = issue
+
+        def wait(self):
+            if self._issue is not None:
+                self._issue()
+                self._issue = None
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
 
     # -- the exchange: every rank contributes its slot of `buf` and receives the others -----------------------
     def _all_gather_slots(self, buf, async_op: bool = False, slot: Optional[int] = None):
         slot = self.slot if slot is None else slot
         lo = self.rank * slot
         mine = buf[lo:lo + slot]
+        if self.exchange == "peers" and slot == self.slot and (buf is self.pos[0] or buf is self.pos[1]):
+            # pulls: the signal NOW (behind what the current stream holds: the finish kernel), the waits and the copy at wait()
+            lib, idx = self.backend.lib, 0 if buf is self.pos[0] else 1
+            with self.torch.cuda.device(self.device):
+                self._peers_call(lib.nb_peers_signal(self._peers, 0, self._stream()))
+
+            def issue():
+                with self.torch.cuda.device(self.device):
+                    self._peers_call(lib.nb_peers_gather(self._peers, 0, idx, self.slot * 16, self._stream()))
+
+            pull = ShardedScene._Pull(issue)
+            if async_op:
+                return pull
+            pull.wait()
+            return None
         if self.dist.get_backend(self.group) == "nccl":
             # RCCL, in place: the send buffer is this rank's slot of the receive buffer (fallback: a copy of the slot)
             return self.dist.all_gather_into_tensor(buf, mine if self.gather_in_place else mine.clone(), group=self.group, async_op=async_op)
@@ -253,6 +345,16 @@ class ShardedScene:
         communicator's stream behind what the current stream holds NOW (the sums of the ranks in front), so launches that
         follow on the current stream overlap with them; the other paths complete before returning."""
         dist, S = self.dist, self.count
+        if self.exchange == "peers" and self._peers_sums:
+            lib = self.backend.lib
+            with self.torch.cuda.device(self.device):
+                self._peers_call(lib.nb_peers_signal(self._peers, 1, self._stream()))   # my chunks are final
+
+            def issue():   # wait for the D ranks behind; one kernel copies their chunks for me
+                with self.torch.cuda.device(self.device):
+                    self._peers_call(lib.nb_peers_ring(self._peers, 1, 2, self.recv.data_ptr(), S * 16, self.partners, self._stream()))
+
+            return [ShardedScene._Pull(issue)], None
         on_host = dist.get_backend(self.group) != "nccl" and self.sums.device.type != "cpu"
         sums = self.sums.cpu() if on_host else self.sums   # rehearsal path (gloo with device buffers): stage through the host
         recv = self.torch.empty(self.recv.shape, dtype=self.recv.dtype) if on_host else self.recv
@@ -309,8 +411,11 @@ class ShardedScene:
         # -- the all-gather: every slot of the buffer must hold its rank's pattern
         buf = self.pos[self.cur ^ 1]
         want = torch.cat([pattern(r, self.slot, 7.0) for r in range(self.world)])
-        for attempt in ("in_place", "out_of_place"):
-            self.gather_in_place = attempt == "in_place"
+        # (with pulls over xGMI the first attempt is the pulls; a mismatch sends BOTH exchanges back to the collectives)
+        for attempt in (("peers",) if self.exchange == "peers" else ()) + ("in_place", "out_of_place"):
+            if attempt != "peers":
+                self.exchange = "collective"
+            self.gather_in_place = attempt != "out_of_place"
             buf.fill_(float("nan"))
             buf[self.rank * self.slot:(self.rank + 1) * self.slot] = want[self.rank * self.slot:(self.rank + 1) * self.slot]
             self._all_gather_slots(buf)
@@ -324,8 +429,10 @@ class ShardedScene:
         if self.partners:
             S = self.count
             want = torch.cat([pattern((self.rank - d) % self.world, S, float(d)) for d in range(1, self.partners + 1)])
-            for attempt in ("grouped", "per_distance"):
-                self.ring_grouped = attempt == "grouped"
+            for attempt in (("peers",) if self.exchange == "peers" and self._peers_sums else ()) + ("grouped", "per_distance"):
+                if attempt != "peers" and self.exchange == "peers":
+                    self.exchange = "collective"   # (the all-gather goes back too: one kind of exchange per step; it was verified above as pulls, the collective is re-verified by the next call)
+                self.ring_grouped = attempt != "per_distance"
                 self.sums[:S].zero_()
                 for d in range(1, self.partners + 1):
                     self.sums[d * S:(d + 1) * S] = pattern(self.rank, S, float(d))
@@ -498,6 +605,71 @@ class ShardedScene:
         if best == "ordered":
             self.sums = self.recv = None
         return best
+
+    def choose_exchange(self, steps: int = 6, warm: int = 2) -> str:
+        """Which exchange is faster on THIS machine for the form the steps take now: the collectives (RCCL's all-gather and grouped
+        send / receive) or pulls over xGMI ordered by stream value waits (``setup_peers``)?  Verifies the pulls on a pattern first,
+        times ``steps`` steps each way on the state in hand (slowest rank; collective), keeps the faster, puts the state back.
+        Returns "peers" or "collective" (``exchange_times``: seconds per step of each; None where the ranks could not map each
+        other's buffers -- another node, no IPC)."""
+        torch = self.torch
+        self.exchange_times = None
+        if self.world == 1:
+            return self.exchange
+        self._wait_pending()
+        if not self.setup_peers():
+            return self.exchange
+        before = self.exchange
+        self.exchange = "peers"
+        if self.verify_exchanges()["all_gather"] != "peers" or self.exchange != "peers":   # the pattern did not arrive through the pulls
+            self.exchange_times = {"peers": None, "collective": None}
+            return self.exchange
+        saved = (self.pos[0].clone(), self.pos[1].clone(), self.vel.clone(), self.cur, self.steps_done, self.velfull_valid)
+        times = {}
+        for kind in ("collective", "peers"):
+            self.exchange = kind
+            self.step_n(warm)
+            self._wait_pending()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self.dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            self.step_n(steps)
+            self._wait_pending()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self.dist.barrier(group=self.group)
+            times[kind] = (time.perf_counter() - t0) / max(1, steps)
+            self._wait_pending()
+            self.pos[0].copy_(saved[0])
+            self.pos[1].copy_(saved[1])
+            self.vel.copy_(saved[2])
+            self.cur, self.steps_done, self.velfull_valid = saved[3], saved[4], saved[5]
+        on_device = self.dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([times["collective"], times["peers"]], dtype=torch.float64, device=self.device if on_device else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        self.exchange_times = {"collective": float(t[0]), "peers": float(t[1])}
+        self.exchange = "peers" if self.exchange_times["peers"] < self.exchange_times["collective"] else "collective"
+        del before
+        return self.exchange
+
+    def close(self) -> None:
+        """drop the mappings of the other ranks' buffers (``setup_peers``); the scene keeps working over the collectives"""
+        if getattr(self, "_peers", None):
+            try:
+                self._wait_pending()
+                if self.device.type == "cuda":
+                    self.torch.cuda.synchronize(self.device)
+                self.backend.lib.nb_peers_destroy(self._peers)
+            finally:
+                self._peers = None
+                self.exchange = "collective"
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def sync(self) -> None:
         """Wait for the queued steps; raises NbError (NB_ERR_STATE) if a kernel reported a failure (``nb_launch_status``)."""

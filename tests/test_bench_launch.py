@@ -61,7 +61,9 @@ def test_bare_gpus_2_rehearsal_prints_one_json_line():
     assert pc["bits_equal"] is True and pc["k"] == line["preheat"]["steps"] + 1 + 2 and pc["checksums"]["xor"] == pc["checksums"]["golden_xor"]
     comm = line["comm"]
     assert comm["backend"] == "gloo" and comm["world"] == 2 and comm["distinct_devices"] == 1 and len(comm["device_uuids"]) == 2
-    assert comm["exchange_paths"] == {"world": 2, "all_gather": "in_place", "ring_exchange": None, "verified": True}
+    # both kinds of exchange were verified on a pattern and timed; on a shared card the pulls over IPC beat gloo's detour through the host
+    assert comm["exchange"]["mapped"] is True and comm["exchange"]["chosen"] in ("peers", "collective") and set(comm["exchange"]["ms_per_step"]) == {"peers", "collective"}
+    assert comm["exchange_paths"]["verified"] and comm["exchange_paths"]["all_gather"] in ("peers", "in_place")
     assert set(line["unpreheated"]) >= {"strict", "fast"}
     assert line["boids_controller"]["split_form"]["value"] > 0
 
@@ -88,8 +90,8 @@ def test_gpus_4_mode_fast_rehearsal_takes_the_pairs_form_as_the_headline():
     # FAST's own parity check: one step of this form against one STRICT step, all bodies; both exchanges verified on a pattern first
     pc = line["parity_check"]
     assert pc["within_tolerance"] is True and pc["max_abs_dr"] < 1e-4 and pc["k"] == 1
-    assert line["comm"]["exchange_paths"] == {"world": 4, "all_gather": "in_place", "ring_exchange": "grouped", "verified": True}
-    assert line["comm"]["world"] == 4 and line["comm"]["distinct_devices"] == 1
+    assert line["comm"]["exchange_paths"]["verified"] and line["comm"]["exchange_paths"]["ring_exchange"] in ("peers", "grouped")
+    assert line["comm"]["world"] == 4 and line["comm"]["distinct_devices"] == 1 and line["comm"]["exchange"]["chosen"] in ("peers", "collective")
 
 
 @pytest.mark.gpu
@@ -129,7 +131,8 @@ def test_gpus_5_strict_ragged_rehearsal_proves_its_parity():
     pc = line["parity_check"]
     assert pc["bits_equal"] is True and pc["k"] == line["preheat"]["steps"] + 1 + 3
     assert line["comm"]["world"] == 5 and line["comm"]["distinct_devices"] == 1 and len(line["comm"]["device_uuids"]) == 5
-    assert line["comm"]["exchange_paths"] == {"world": 5, "all_gather": "in_place", "ring_exchange": None, "verified": True}
+    assert line["comm"]["exchange_paths"]["verified"] and line["comm"]["exchange_paths"]["all_gather"] in ("peers", "in_place")
+    assert line["comm"]["exchange"]["mapped"] is True
     assert line["roofline"]["kernel"] == "step_strict_bc_kernel"
 
 

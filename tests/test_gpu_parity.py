@@ -1303,6 +1303,86 @@ def test_multirank_on_one_gpu_fast_with_overlapped_exchange(tmp_path, nb, oracle
         assert np.abs(got["pos"] - p_ref).max() <= 2e-5, f"rank {r}"
 
 
+def _peers_worker(rank, world, port, n, k, mode, out_dir, what):
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import nenbody_amd
+
+        torch.cuda.set_device(0)
+        if what.startswith("ring"):
+            os.environ["NB_RING"] = "1"       # (sets this small keep the ordered fold by themselves)
+            nenbody_amd.reload_env()
+        pos, vel = nenbody_amd.init_state(n, 99)
+        p = nenbody_amd.default_params(mode=mode)
+        if what == "choose":   # the collectives (here: gloo through the host) against the pulls, timed; the state must come back
+            sc = nenbody_amd.ShardedScene(pos, vel, p)
+            sc.step()
+            before = (sc.positions().copy(), sc.velocities().copy())
+            chosen = sc.choose_exchange(steps=2, warm=1)
+            assert chosen in ("peers", "collective") and set(sc.exchange_times) == {"peers", "collective"} and sc.exchange == chosen
+            assert sc.exchange_report["all_gather"] == "peers" and sc.exchange_report["verified"]
+            assert (sc.positions() == before[0]).all() and (sc.velocities() == before[1]).all()
+            sc.step_n(k - 1)
+        else:
+            sc = nenbody_amd.ShardedScene(pos, vel, p, exchange="peers", ring=True if what.startswith("ring") else None,
+                                          ring_overlap=what == "ring_overlap", overlap=what == "overlap")
+            assert sc.exchange == "peers"
+            rep = sc.verify_exchanges()
+            assert rep["all_gather"] == "peers" and rep["ring_exchange"] == ("peers" if sc.partners else None) and sc.exchange == "peers", rep
+            real = dist.all_gather_into_tensor
+            calls = []
+            dist.all_gather_into_tensor = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+            sc.step_n(k)
+            sc.sync()
+            dist.all_gather_into_tensor = real
+            assert not calls, "a step went through the collective"
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pos=sc.positions(), vel=sc.velocities())
+        sc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,what", [(2, 4096, "strict"), (3, 1000, "strict"), (3, 20000, "overlap"), (4, 16384, "ring"), (4, 16384, "ring_overlap"),
+                                          (2, 8192, "ring_overlap"), (3, 4096, "choose")])
+def test_sharded_scene_pulls_its_exchanges_over_ipc(tmp_path, nb, oracle, world, n, what):
+    """ShardedScene(exchange="peers"): the all-gather and the pairs form's second exchange as pulls over IPC-mapped buffers, ordered by
+    stream value waits (nb_peers_*), between PROCESSES sharing the one GPU; torch.distributed only carries the handles.  Every step
+    is checked not to touch a collective; STRICT (a ragged world too) bit-identical to the oracle, the FAST forms -- ordered fold with
+    the pull behind the own slot's fold, the pairs form in sequence and in phases -- at FAST's tolerance; verify_exchanges reports the
+    pulls verified; choose_exchange times them against the collectives and puts the state back."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k = 3
+    mode = nb.NB_MODE_STRICT if what in ("strict", "choose") else nb.NB_MODE_FAST
+    mp.spawn(_peers_worker, args=(world, port, n, k, mode, str(tmp_path), what), nprocs=world, join=True)
+    pos, vel = nb.init_state(n, 99)
+    p_ref, v_ref = oracle.run(pos, vel, k)
+    acc = np.abs(v_ref - vel).max()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        if mode == nb.NB_MODE_STRICT:
+            assert_bits_equal(got["pos"], p_ref, f"rank {r} positions")
+            assert_bits_equal(got["vel"], v_ref, f"rank {r} velocities")
+        else:
+            assert np.abs(got["vel"] - v_ref).max() <= 4e-5 * acc + 1e-9, f"rank {r}"
+            assert np.abs(got["pos"] - p_ref).max() <= 2e-5, f"rank {r}"
+
+
 def _rccl_world_of_one(rank, port, n, k, out_dir):
     import sys
 
