@@ -147,6 +147,7 @@ PROTOTYPES = {
     "nb_peers_last_error": (c_char_p, [c_void_p]),
     "nb_peers_export": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_int, c_void_p]),
     "nb_peers_import": (c_int, [c_void_p, c_void_p]),
+    "nb_peers_probe": (c_int, [c_void_p, c_uint32]),
     "nb_peers_signal": (c_int, [c_void_p, c_int, c_void_p]),
     "nb_peers_gather": (c_int, [c_void_p, c_int, c_int, c_size_t, c_void_p]),
     "nb_peers_ring": (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),

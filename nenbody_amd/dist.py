@@ -278,6 +278,17 @@ class ShardedScene:
                 ok, self.peers_error = False, lib.nb_peers_last_error(handle).decode()
         elif ok:
             ok, self.peers_error = False, "another rank could not export its buffers"
+        every_imported = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(every_imported, op=dist.ReduceOp.MIN, group=self.group)
+        if bool(every_imported.item()):
+            # first contact with a deadline: a signal / wait / one-record pull round on a stream of its own -- if a peer's word never
+            # becomes visible, that stream alone stays blocked and the steps keep their collectives
+            with torch.cuda.device(self.device):
+                rc = lib.nb_peers_probe(handle, 10000)
+            if rc != _lib.NB_OK:
+                ok, self.peers_error = False, lib.nb_peers_last_error(handle).decode()
+        elif ok:
+            ok, self.peers_error = False, "another rank could not map the buffers"
         on_device = dist.get_backend(self.group) == "nccl"
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_device else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
