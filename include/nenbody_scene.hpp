@@ -177,6 +177,16 @@ public:
         return c;
     }
     void set_pairs(bool on) { check_sh(nb_shard_set_pairs(sh_, on ? 1 : 0)); }  // name the form (run-to-run identical FAST bits)
+    // both exchanges as pulls over xGMI, no collective library (include/nenbody.h): every rank's peer_blob() travels to every rank by the
+    // host's own channel, rank-major, into peer_import(); all ranks in processes of one node
+    std::vector<unsigned char> peer_blob()
+    {
+        std::vector<unsigned char> b(nb_peers_blob_bytes());
+        check_sh(nb_shard_peer_export(sh_, b.data()));
+        return b;
+    }
+    void peer_import(const std::vector<unsigned char> &all_blobs_rank_major) { check_sh(nb_shard_peer_import(sh_, all_blobs_rank_major.data())); }
+    void use_peers(bool on) { check_sh(nb_shard_use_peers(sh_, on ? 1 : 0)); }
     // waits; throws Error(NB_ERR_STATE) if a kernel of this shard reported a failure (a block-chain wave gave up waiting)
     void sync() { check_sh(nb_shard_sync(sh_)); }
     // all n positions (the replica); this rank's velocities and model matrices
