@@ -225,6 +225,44 @@ def test_shard_argument_contract_and_no_device(nb):
         nb.comm_id()
 
 
+def test_round5_entry_points_validate_before_touching_the_device(nb):
+    """The entry points of round 5 -- the pairs form's phases, the exchanges as pulls, the shard's verify / choose -- check their
+    arguments on the host and say NB_ERR_INVALID (or, with sound arguments and no GPU, NB_ERR_NO_DEVICE) before any device work."""
+    from nenbody_amd import _lib
+
+    lib = _lib.load()
+    fast, strict = nb.default_params(mode=nb.NB_MODE_FAST), nb.default_params()
+    # which shapes run their step in phases is host arithmetic: every rank count of config 4, none of config 5, never STRICT
+    assert [lib.nb_ring_phased(ctypes.byref(fast), 131072, 0, 131072 // w) for w in (2, 4, 8)] == [1, 1, 1]
+    assert [lib.nb_ring_phased(ctypes.byref(fast), 1 << 20, 0, (1 << 20) // w) for w in (2, 4, 8)] == [0, 0, 0]
+    assert lib.nb_ring_phased(ctypes.byref(strict), 131072, 0, 16384) == 0 and lib.nb_ring_phased(ctypes.byref(fast), 131072, 100, 16384) == 0
+    # the rows' size is the same on every rank of a job (a host may size one buffer for all)
+    assert len({lib.nb_ring_scratch_bytes(ctypes.byref(fast), 131072, r * 16384, 16384) for r in range(8)}) == 1
+    one = ctypes.c_void_p(16)   # (never dereferenced: the checks come first)
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_OWN, None, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, 0, one, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, 4, one, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(strict), 131072, 0, 16384, _lib.NB_RING_REST, one, one, one, 1 << 30, None) == _lib.NB_ERR_UNSUPPORTED
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_REST, one, one, one, 64, None) == _lib.NB_ERR_INVALID   # scratch too small
+    # the exchanges as pulls
+    assert lib.nb_peers_blob_bytes() >= 64 * 5
+    p = ctypes.c_void_p()
+    for rank, world in ((0, 0), (2, 2), (-1, 2), (0, 17)):
+        assert lib.nb_peers_create(rank, world, ctypes.byref(p)) == _lib.NB_ERR_INVALID and not p.value
+    assert lib.nb_peers_create(0, 2, None) == _lib.NB_ERR_INVALID
+    for fn, args in ((lib.nb_peers_export, (None, None, None, 1, None)), (lib.nb_peers_import, (None, None)), (lib.nb_peers_probe, (None, 10)),
+                     (lib.nb_peers_signal, (None, 0, None)), (lib.nb_peers_gather, (None, 0, 0, 16, None)), (lib.nb_peers_ring, (None, 0, 0, None, 16, 1, None)),
+                     (lib.nb_shard_peer_export, (None, None)), (lib.nb_shard_peer_import, (None, None)), (lib.nb_shard_use_peers, (None, 1)),
+                     (lib.nb_shard_verify_exchanges, (None, None, None)), (lib.nb_shard_pairs_overlapped, (None,))):
+        assert fn(*args) == _lib.NB_ERR_INVALID, fn
+    assert lib.nb_shard_choose_form(None, 4, None, None) == _lib.NB_ERR_INVALID
+    lib.nb_peers_destroy(None)
+    assert lib.nb_peers_last_error(None) is not None
+    if lib.nb_device_count() == 0:
+        assert lib.nb_peers_create(0, 2, ctypes.byref(p)) == _lib.NB_ERR_NO_DEVICE and not p.value
+        assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_OWN, one, one, one, 1 << 30, None) == _lib.NB_ERR_NO_DEVICE
+
+
 def test_debug_overrides_are_read_once_and_reloaded_on_request(nb, monkeypatch):
     """The NB_* kernel-form overrides are parsed once per process; nb_debug_reload_env() (which the test suite's monkeypatch
     calls for NB_* names) makes the library read them again.  Pure host arithmetic: visible through nb_scratch_bytes."""
