@@ -1357,745 +1357,9 @@ NB_EXPORT int nb_download(nb_ctx *ctx, float *pos_xyz, float *vel_xyz, float *in
     return check_status(&ctx->status, &ctx->err);
 }
 
-// ---- one-call drop-ins (src/main.rs:404-410, 443-449) ---------------------------------------------------
-namespace {
-// The drop-in calls keep their device contexts between frames.  A host may alternate controllers or entity counts from
-// frame to frame (the reference swaps controllers by editing main.rs:925), so a few contexts are kept, keyed by controller,
-// body count and constants; the least recently used slot is rebuilt (stream + five allocations) only when a FOURTH shape shows up.
-// The kept contexts hold their device memory -- a FAST whole set in the pairs form has n x n / 2048 x 12 B of rows: 100 MB at
-// 131 072 bodies, 0.4 GB at 262 144 -- so the slots OTHER than the one just used are also dropped, least recently used first,
-// while the kept contexts together exceed kUpdateCacheBytes (round 4: a host alternating large shapes pinned up to 1.2 GB).
-struct UpdateSlot {
-    nb_ctx *ctx = nullptr;
-    int kind = -1;  // 0 = n-body, 1 = boids, 2 = random walk
-    nb_params p{};
-    uint64_t used = 0;
-    size_t bytes = 0;  // device memory the context holds (records, matrices, staging, scratch)
-};
-constexpr size_t kUpdateCacheBytes = (size_t)256 << 20;
-struct UpdateCache {
-    std::mutex mu;
-    static constexpr int kSlots = 3;
-    UpdateSlot slot[kSlots];
-    uint64_t clock = 0;
-    nb_ctx *last = nullptr;  // whose error message update_fail reports
-    std::vector<float> pos_full, vel_full, tmp;
-    // update_instance_random (three slices, main.rs:381-385): the library's own stream position
-    uint64_t random_seed = 0x6e656e626f6479ull, random_calls = 0;
-};
-// never destroyed: a static destructor could run after the HIP runtime's own teardown
-UpdateCache &update_cache()
-{
-    static UpdateCache *c = new UpdateCache();
-    return *c;
-}
+#include "nb_dropin.inc"
 
-int update_fail(UpdateCache &uc, const char *who, int rc)
-{
-    g_tls_error = std::string(who) + ": " + (uc.last ? uc.last->err : g_tls_error);
-    return rc;
-}
-
-// the context for (kind, n, p): a kept one, or a new one in the least recently used slot.  uc.mu is held.
-int update_context(UpdateCache &uc, int kind, uint32_t n, const nb_params &p, nb_ctx **out)
-{
-    UpdateSlot *victim = &uc.slot[0];
-    for (UpdateSlot &sl : uc.slot) {
-        if (sl.ctx && sl.kind == kind && sl.ctx->n == n && std::memcmp(&sl.p, &p, sizeof(p)) == 0) {
-            sl.used = ++uc.clock;
-            uc.last = *out = sl.ctx;
-            return NB_OK;
-        }
-        if (!sl.ctx ? victim->ctx != nullptr : (victim->ctx && sl.used < victim->used)) victim = &sl;
-    }
-    if (victim->ctx) nb_destroy(victim->ctx);
-    victim->ctx = nullptr;
-    uc.last = nullptr;
-    int rc = nb_create(n, 1, &p, &victim->ctx);
-    if (rc != NB_OK) return rc;
-    victim->kind = kind;
-    victim->p = p;
-    victim->used = ++uc.clock;
-    Plan pl{};
-    std::string ignored;
-    victim->bytes = (size_t)n * (3 * sizeof(float4) + 16 * sizeof(float) + 22 * sizeof(float)) +
-                    (make_plan(p, n, n, &pl, &ignored) == NB_OK ? plan_scratch_bytes(pl, n) : 0);
-    for (;;) {  // the new context stays; older ones go while the cache is over its budget
-        size_t total = 0;
-        UpdateSlot *oldest = nullptr;
-        for (UpdateSlot &sl : uc.slot) {
-            if (!sl.ctx) continue;
-            total += sl.bytes;
-            if (&sl != victim && (!oldest || sl.used < oldest->used)) oldest = &sl;
-        }
-        if (total <= kUpdateCacheBytes || !oldest) break;
-        nb_destroy(oldest->ctx);
-        oldest->ctx = nullptr;
-        oldest->bytes = 0;
-    }
-    uc.last = *out = victim->ctx;
-    return NB_OK;
-}
-
-// upload + one step + download with ONE host<->device copy each way and one wait: the per-frame cost of the drop-in
-// calls at the reference's own sizes (entity_count 100 .. 2048) is all latency, so every separate copy and
-// synchronisation of nb_upload / nb_download shows.  pos / vel: n bodies each; outputs: the first `count` bodies.
-// upload + one step + download with ONE host<->device copy each way, one launch to unpack, one to pack, and one wait: the
-// per-frame cost of the drop-in calls at the reference's own sizes (entity_count 100 .. 2048) is all latency, so every
-// separate copy, launch and synchronisation shows.  (Replaying the five operations as a captured hipGraph was measured
-// too: 37 us per call at N = 100 against 30 us with plain launches, no difference at N = 2 048 -- not adopted.)
-// pos / vel: n bodies each; outputs: the first `count` bodies.
-// kind: 0 = n-body step, 1 = boids step, 2 = random-walk step (stream (seed, step, n) of nb_step_random)
-int update_roundtrip(nb_ctx *c, int kind, const nb_boids_params *bp, const float *pos, const float *vel, size_t count,
-                     float *pos_out, float *vel_out, float *inst_out, uint64_t seed = 0, uint64_t step = 0)
-{
-    const size_t n = c->n, xyz = 3 * sizeof(float);
-    int rc = ensure_xfer(c);
-    if (rc != NB_OK) return rc;
-    std::memcpy(c->hxfer, pos, n * xyz);
-    std::memcpy(c->hxfer + 3 * n, vel, n * xyz);
-    c->cur = 0;
-    c->uploaded = true;
-    c->steps = 0;
-    // the pack / unpack kernels read and write the pinned host buffer THROUGH THE BUS themselves: the two DMA operations of a
-    // staged copy cost more in fixed latency than these few kilobytes cost in bandwidth (kZeroCopyMax)
-    const bool zero_copy = small_set_zero_copy(c->n);
-    float *const in = zero_copy ? c->hxfer_dev : c->xfer, *const out = zero_copy ? c->hxfer_dev : c->xfer;
-    if (!zero_copy) NB_HIP(c, hipMemcpyAsync(c->xfer, c->hxfer, 2 * n * xyz, hipMemcpyHostToDevice, c->stream));
-    NB_HIP(c, nbk::launch_import(c->n, in, in + 3 * n, c->pos[0], c->vel, c->stream));
-    if (kind == 2) c->steps = step;  // the random walk's stream is indexed by the step counter
-    rc = kind == 2 ? nb_step_random(c, 1, seed) : kind == 1 ? nb_step_boids(c, 1, bp) : nb_step(c, 1);
-    if (rc != NB_OK) return rc;
-    // the sticky status word of this context's block-chain launches comes home in the same buffer: no second wait per frame
-    const bool with_status = c->status.dirty && c->status.w;
-    const nbk::ExportDone done = export_done(c, small_set_poll(c->n));
-    NB_HIP(c, nbk::launch_export(c->n, c->pos[c->cur], c->vel, (float4 *)out, out + 16 * n, out + 19 * n, with_status ? c->status.w : nullptr,
-                                 with_status ? (uint32_t *)(out + 22 * n) : nullptr, c->stream, overrides().inst_device_libm.on() ? 1u : 0u, done));
-    if (!zero_copy)
-        NB_HIP(c, hipMemcpyAsync(c->hxfer, c->xfer, (n * 22 + (with_status ? 1 : 0)) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    rc = wait_export(c, done);
-    if (rc != NB_OK) return rc;
-    rc = status_from_tail(c, with_status);
-    if (rc != NB_OK) return rc;
-    std::memcpy(inst_out, c->hxfer, count * 16 * sizeof(float));
-    std::memcpy(pos_out, c->hxfer + 16 * n, count * xyz);
-    std::memcpy(vel_out, c->hxfer + 19 * n, count * xyz);
-    return NB_OK;
-}
-
-int update_common(const char *who, bool boids, float *inst, size_t n_inst, float *pos, size_t n_pos, float *opos, size_t n_opos,
-                  float *vel, size_t n_vel, float *ovel, size_t n_ovel, const nb_params *np, const nb_boids_params *bp)
-{
-    if (n_opos != n_pos || n_ovel != n_vel) {  // copy_from_slice (main.rs:415-416, 459-460) panics
-        g_tls_error = std::string(who) + ": source slice length does not match destination slice length (" +
-                      (n_opos != n_pos ? "old_positions vs positions" : "old_velocities vs velocities") + ")";
-        return NB_ERR_INVALID;
-    }
-    if ((n_pos && (!pos || !opos)) || (n_vel && (!vel || !ovel)) || (n_inst && !inst)) {
-        g_tls_error = std::string(who) + ": null array with a nonzero length";
-        return NB_ERR_INVALID;
-    }
-    const size_t xyz = 3 * sizeof(float);
-    if (n_pos) std::memcpy(opos, pos, n_pos * xyz);  // main.rs:415 / 459
-    if (n_vel) std::memcpy(ovel, vel, n_vel * xyz);  // main.rs:416 / 460
-    const size_t count = std::min(n_inst, std::min(n_pos, n_vel));  // zip, main.rs:420-423 / 465-469
-    if (count == 0) return NB_OK;
-    // The set the device folds over.  n-body: old_positions (main.rs:425).  boids: the position folds run over
-    // old_positions.iter() (main.rs:471, 482) and the velocity fold over old_velocities.iter() (main.rs:494), each with its own
-    // length -- the reference never indexes one slice by the other's length -- so the device set is the longer of the two
-    // and the shorter snapshot is padded with NaN records: a NaN distance fails every `dist < radius` test (main.rs:475, 486,
-    // 498), so a padding record contributes to no sum and no count, exactly like an element that is not there.
-    const size_t n_set = boids ? std::max(n_pos, n_vel) : n_pos;
-    if (n_set > 0xffffffffull) {
-        g_tls_error = std::string(who) + ": more than 2^32-1 bodies";
-        return NB_ERR_INVALID;
-    }
-    nb_params p;
-    if (np)
-        p = *np;
-    else
-        nb_default_params(&p);
-
-    UpdateCache &uc = update_cache();
-    std::lock_guard<std::mutex> lock(uc.mu);
-    const uint32_t n = (uint32_t)n_set;
-    nb_ctx *ctx = nullptr;
-    int rc = update_context(uc, boids ? 1 : 0, n, p, &ctx);
-    if (rc != NB_OK) return update_fail(uc, who, rc);
-    const float *pos_src = opos, *vel_src = ovel;
-    if (n_pos < n_set) {  // boids only
-        uc.pos_full.assign(n_set * 3, std::nanf(""));
-        std::memcpy(uc.pos_full.data(), opos, n_pos * xyz);
-        pos_src = uc.pos_full.data();
-    }
-    if (n_vel < n_set) {
-        // n-body: bodies past the zip are computed and dropped; give them a velocity to carry.  boids: see above.
-        uc.vel_full.assign(n_set * 3, boids ? std::nanf("") : 0.f);
-        std::memcpy(uc.vel_full.data(), ovel, n_vel * xyz);
-        vel_src = uc.vel_full.data();
-    }
-    // Small sets are all latency: one copy each way through pinned memory (41 us per call at N = 100, 87 us at 2 048,
-    // against 104 / 143 us with separate copies).  Large sets are all bandwidth: copy straight from and to the caller's
-    // arrays (at N = 131 072 the detour through the pinned buffer costs 0.7 ms).  Measured: tools/crossover.py.
-    if (n <= kRoundtripMax) {
-        rc = update_roundtrip(ctx, boids ? 1 : 0, bp, pos_src, vel_src, count, pos, vel, inst);
-        if (rc != NB_OK) return update_fail(uc, who, rc);
-        return NB_OK;
-    }
-    rc = nb_upload(ctx, pos_src, vel_src);
-    if (rc == NB_OK) rc = boids ? nb_step_boids(ctx, 1, bp) : nb_step(ctx, 1);
-    if (rc != NB_OK) return update_fail(uc, who, rc);
-    if (count == n_set) {  // the usual case: all three slices as long as the set
-        rc = nb_download(ctx, pos, vel, inst);
-        if (rc != NB_OK) return update_fail(uc, who, rc);
-        return NB_OK;
-    }
-    uc.tmp.resize(n_set * 22);
-    float *pos_tmp = uc.tmp.data(), *vel_tmp = pos_tmp + 3 * n_set, *inst_tmp = pos_tmp + 6 * n_set;
-    rc = nb_download(ctx, pos_tmp, vel_tmp, inst_tmp);
-    if (rc != NB_OK) return update_fail(uc, who, rc);
-    std::memcpy(pos, pos_tmp, count * xyz);
-    std::memcpy(vel, vel_tmp, count * xyz);
-    std::memcpy(inst, inst_tmp, count * 16 * sizeof(float));
-    return NB_OK;
-}
-}  // namespace
-
-NB_EXPORT int nb_update_instance_nbody(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                                       float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz,
-                                       size_t n_velocities, float *old_velocities_xyz, size_t n_old_velocities,
-                                       const nb_params *params)
-{
-    return update_common("nb_update_instance_nbody", false, instances_16n, n_instances, positions_xyz, n_positions,
-                         old_positions_xyz, n_old_positions, velocities_xyz, n_velocities, old_velocities_xyz, n_old_velocities,
-                         params, nullptr);
-}
-
-NB_EXPORT int nb_update_instance_boids(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                                       float *old_positions_xyz, size_t n_old_positions, float *velocities_xyz,
-                                       size_t n_velocities, float *old_velocities_xyz, size_t n_old_velocities,
-                                       const nb_boids_params *params)
-{
-    return update_common("nb_update_instance_boids", true, instances_16n, n_instances, positions_xyz, n_positions,
-                         old_positions_xyz, n_old_positions, velocities_xyz, n_velocities, old_velocities_xyz, n_old_velocities,
-                         nullptr, params);
-}
-
-// update_instance_random (src/main.rs:381-402): three slices, no snapshots; the zip (:386-389) bounds which bodies move.
-namespace {
-int update_random_common(const char *who, float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                         float *velocities_xyz, size_t n_velocities, bool own_stream, uint64_t seed, uint64_t step)
-{
-    if ((n_positions && !positions_xyz) || (n_velocities && !velocities_xyz) || (n_instances && !instances_16n)) {
-        g_tls_error = std::string(who) + ": null array with a nonzero length";
-        return NB_ERR_INVALID;
-    }
-    const size_t count = std::min(n_instances, std::min(n_positions, n_velocities));  // zip, main.rs:386-389
-    if (count == 0) return NB_OK;
-    if (count > 0xffffffffull) {
-        g_tls_error = std::string(who) + ": more than 2^32-1 bodies";
-        return NB_ERR_INVALID;
-    }
-    nb_params p;
-    nb_default_params(&p);
-    UpdateCache &uc = update_cache();
-    std::lock_guard<std::mutex> lock(uc.mu);
-    if (own_stream) {  // the three-slice form: the library keeps the seed and counts the calls
-        seed = uc.random_seed;
-        step = uc.random_calls;
-    }
-    const uint32_t n = (uint32_t)count;  // every body walks on its own: the device set is exactly the bodies that move
-    nb_ctx *ctx = nullptr;
-    int rc = update_context(uc, 2, n, p, &ctx);
-    if (rc != NB_OK) return update_fail(uc, who, rc);
-    if (n <= kRoundtripMax) {
-        rc = update_roundtrip(ctx, 2, nullptr, positions_xyz, velocities_xyz, count, positions_xyz, velocities_xyz, instances_16n, seed, step);
-    } else {
-        rc = nb_upload(ctx, positions_xyz, velocities_xyz);
-        if (rc == NB_OK) {
-            ctx->steps = step;
-            rc = nb_step_random(ctx, 1, seed);
-        }
-        if (rc == NB_OK) rc = nb_download(ctx, positions_xyz, velocities_xyz, instances_16n);
-    }
-    if (rc != NB_OK) return update_fail(uc, who, rc);
-    if (own_stream) uc.random_calls++;
-    return NB_OK;
-}
-}  // namespace
-
-NB_EXPORT int nb_update_instance_random(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                                        float *velocities_xyz, size_t n_velocities)
-{
-    return update_random_common("nb_update_instance_random", instances_16n, n_instances, positions_xyz, n_positions, velocities_xyz,
-                                n_velocities, true, 0, 0);
-}
-
-NB_EXPORT int nb_update_instance_random_seeded(float *instances_16n, size_t n_instances, float *positions_xyz, size_t n_positions,
-                                               float *velocities_xyz, size_t n_velocities, uint64_t seed, uint64_t step)
-{
-    return update_random_common("nb_update_instance_random_seeded", instances_16n, n_instances, positions_xyz, n_positions,
-                                velocities_xyz, n_velocities, false, seed, step);
-}
-
-NB_EXPORT void nb_update_random_seed(uint64_t seed)
-{
-    UpdateCache &uc = update_cache();
-    std::lock_guard<std::mutex> lock(uc.mu);
-    uc.random_seed = seed;
-    uc.random_calls = 0;
-}
-
-NB_EXPORT void nb_update_release(void)
-{
-    UpdateCache &uc = update_cache();
-    std::lock_guard<std::mutex> lock(uc.mu);
-    for (UpdateSlot &sl : uc.slot) {
-        if (sl.ctx) nb_destroy(sl.ctx);
-        sl = UpdateSlot();
-    }
-    uc.last = nullptr;
-    uc.pos_full = std::vector<float>();
-    uc.vel_full = std::vector<float>();
-    uc.tmp = std::vector<float>();
-}
-
-NB_EXPORT int nb_selftest_divide(const nb_params *params, uint64_t pairs, uint64_t seed, uint64_t *mismatches, float *bad_pair)
-{
-    if (!mismatches) {
-        g_tls_error = "nb_selftest_divide: mismatches is null";
-        return NB_ERR_INVALID;
-    }
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    p.mode = NB_MODE_STRICT;
-    Plan pl;
-    int rc = make_plan(p, 1024, 1024, &pl, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (pl.force_ieee && !overrides().strict_force_ieee.on()) {
-        g_tls_error = "nb_selftest_divide: these parameters have no guarded range (STRICT always divides with '/')";
-        return NB_ERR_UNSUPPORTED;
-    }
-    if (pl.force_ieee) {  // forced by the environment only: recompute the range without the override is not possible here
-        g_tls_error = "nb_selftest_divide: unset NB_STRICT_FORCE_IEEE";
-        return NB_ERR_UNSUPPORTED;
-    }
-    rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    // what the kernels can meet inside the guard (see make_plan):
-    //   d = |dp|^2 + bias  in [2^c, 2^max(2b+4, c+2)),   n = dx*G, nonzero dx in [2^(a-23), 2^(b+1)]  ->  |n| in [2^(a-23+g), 2^(b+g+2))
-    const int d_lo = pl.guard_c, d_hi = std::max(2 * pl.guard_b + 4, pl.guard_c + 2) - 1;
-    const int n_lo = pl.guard_a - 23 + pl.guard_g, n_hi = pl.guard_b + pl.guard_g + 1;
-    unsigned long long *d_bad = nullptr;
-    float *d_pair = nullptr;
-    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_pair, 2 * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(d_pair, 0, 2 * sizeof(float));
-    const uint32_t blocks = 4096;
-    const uint64_t threads = (uint64_t)blocks * 256u;
-    uint64_t per_thread = (pairs + threads - 1) / threads;
-    if (per_thread > 0xffffffffull) per_thread = 0xffffffffull;
-    const bool control = overrides().selftest_control.on();  // NB_SELFTEST_CONTROL=1: compare the UNCORRECTED product n*r instead (control arm: must report mismatches)
-    if (e == hipSuccess)
-        e = nbk::launch_divide_selftest(blocks, seed, (uint32_t)per_thread, d_lo, d_hi, n_lo, n_hi, d_bad, d_pair, control, nullptr);
-    unsigned long long bad = 0;
-    float pair[2] = {0.f, 0.f};
-    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(pair, d_pair, sizeof(pair), hipMemcpyDeviceToHost);
-    if (d_bad) (void)hipFree(d_bad);
-    if (d_pair) (void)hipFree(d_pair);
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_selftest_divide: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    *mismatches = bad;
-    if (bad_pair) {
-        bad_pair[0] = pair[0];
-        bad_pair[1] = pair[1];
-    }
-    return NB_OK;
-}
-
-NB_EXPORT int nb_selftest_ladder(uint32_t first_significand, uint32_t count, uint64_t *mismatches, float *bad_pair)
-{
-    if (!mismatches || count == 0 || first_significand >= (1u << 23) || count > (1u << 23) - first_significand) {
-        g_tls_error = "nb_selftest_ladder: need mismatches != NULL and a non-empty range of denominator significands inside [0, 2^23)";
-        return NB_ERR_INVALID;
-    }
-    int rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    const bool control = overrides().selftest_control.on();  // NB_SELFTEST_CONTROL=1: the same steps on the UNREFINED reciprocal (control arm: must report mismatches)
-    unsigned long long *d_bad = nullptr;
-    float *d_pair = nullptr;
-    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_pair, 2 * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(d_pair, 0, 2 * sizeof(float));
-    const uint32_t slab = 1u << 13;  // 2^36 pairs per launch: a fraction of a second each, so no launch runs long
-    for (uint32_t done = 0; e == hipSuccess && done < count; done += slab) {
-        e = nbk::launch_ladder_exhaustive(first_significand + done, std::min(slab, count - done), control, d_bad, d_pair, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
-    unsigned long long bad = 0;
-    float pair[2] = {0.f, 0.f};
-    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(pair, d_pair, sizeof(pair), hipMemcpyDeviceToHost);
-    if (d_bad) (void)hipFree(d_bad);
-    if (d_pair) (void)hipFree(d_pair);
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_selftest_ladder: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    *mismatches = bad;
-    if (bad_pair) {
-        bad_pair[0] = pair[0];
-        bad_pair[1] = pair[1];
-    }
-    return NB_OK;
-}
-
-// Do the model matrices of THIS device equal what THIS host's C library computes?  nb_libm.h restates one libm (glibc 2.35, the
-// build of sinf / cosf it selects on CPUs with FMA); a host with another one -- musl, a glibc with CORE-MATH's correctly rounded
-// sinf -- rounds a few arguments in a billion differently.  `count` velocities (the step's own range, every binade 2^-40..2^40,
-// near-axis directions) go through nb_launch_instances and through the host's atan2f / sinf / cosf; *mismatches = matrices whose
-// rotation entries differ in some bit (0 on the hosts this was built for); bad_velocity, if non-NULL, receives one offender (x, y).
-NB_EXPORT int nb_selftest_matrices(uint32_t count, uint64_t seed, uint64_t *mismatches, float *bad_velocity)
-{
-    if (!mismatches || count == 0 || count > (1u << 26)) {
-        g_tls_error = "nb_selftest_matrices: need mismatches != NULL and 0 < count <= 2^26";
-        return NB_ERR_INVALID;
-    }
-    int rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    std::vector<float4> pos(count), vel(count);
-    uint64_t st = seed;
-    for (uint32_t i = 0; i < count; ++i) {
-        float x, y;
-        switch (i & 3u) {
-        case 0: x = uniform_f32(st, -0.2f, 0.2f), y = uniform_f32(st, -0.2f, 0.2f); break;   // what a step produces
-        case 1: {                                                                              // every binade, either sign
-            const int ex = (int)(splitmix64(st) % 81u) - 40, ey = (int)(splitmix64(st) % 81u) - 40;
-            x = std::ldexp(uniform_f32(st, 1.0f, 2.0f), ex) * ((splitmix64(st) & 1u) ? -1.f : 1.f);
-            y = std::ldexp(uniform_f32(st, 1.0f, 2.0f), ey) * ((splitmix64(st) & 1u) ? -1.f : 1.f);
-            break;
-        }
-        case 2: {                                                                              // any direction, any length
-            const float ang = uniform_f32(st, -3.14159f, 3.14159f), r = std::ldexp(1.0f, (int)(splitmix64(st) % 41u) - 20);
-            x = r * std::cos(ang), y = r * std::sin(ang);
-            break;
-        }
-        default: {                                                                             // near the axes and the diagonals
-            static const float bx[8] = {1, 0, -1, 0, 1, -1, 1, -1}, by[8] = {0, 1, 0, -1, 1, 1, -1, -1};
-            const uint32_t k = (uint32_t)(splitmix64(st) & 7u);
-            const float eps = std::ldexp(1.0f, -(int)(splitmix64(st) % 30u) - 1);
-            x = bx[k] + uniform_f32(st, -1.f, 1.f) * eps, y = by[k] + uniform_f32(st, -1.f, 1.f) * eps;
-        }
-        }
-        vel[i] = make_float4(x, y, 0.f, 0.f);
-        pos[i] = make_float4(uniform_f32(st, -100.f, 100.f), uniform_f32(st, -100.f, 100.f), 0.f, 0.f);
-    }
-    float4 *d_pos = nullptr, *d_vel = nullptr, *d_inst = nullptr;
-    std::vector<float4> inst((size_t)count * 4);
-    hipError_t e = hipMalloc((void **)&d_pos, (size_t)count * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_vel, (size_t)count * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_inst, (size_t)count * 4 * sizeof(float4));
-    if (e == hipSuccess) e = hipMemcpy(d_pos, pos.data(), (size_t)count * sizeof(float4), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_vel, vel.data(), (size_t)count * sizeof(float4), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = nbk::launch_instances(count, d_pos, d_vel, d_inst, nullptr, 0u);
-    if (e == hipSuccess) e = hipMemcpy(inst.data(), d_inst, (size_t)count * 4 * sizeof(float4), hipMemcpyDeviceToHost);
-    for (void *p : {(void *)d_pos, (void *)d_vel, (void *)d_inst})
-        if (p) (void)hipFree(p);
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_selftest_matrices: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    uint64_t bad = 0;
-    for (uint32_t i = 0; i < count; ++i) {
-        const float theta = std::atan2(vel[i].y, vel[i].x);   // the float overloads: the host's atan2f / sinf / cosf
-        const float sn = std::sin(theta), cs = std::cos(theta);
-        const float4 c0 = inst[(size_t)i * 4], c1 = inst[(size_t)i * 4 + 1];
-        const float want[4] = {cs, sn, -sn, cs}, got[4] = {c0.x, c0.y, c1.x, c1.y};
-        if (std::memcmp(want, got, sizeof(want)) != 0) {
-            if (bad == 0 && bad_velocity) bad_velocity[0] = vel[i].x, bad_velocity[1] = vel[i].y;
-            ++bad;
-        }
-    }
-    *mismatches = bad;
-    return NB_OK;
-}
-
-// The device's atan2f / sinf / cosf / atanf (nb_libm.h) against THIS host's C library, argument by argument: `count` consecutive
-// binary32 bit patterns from `first` (count = 0 with first = 0: all 2^32) through function fn -- 0 sinf, 1 cosf, 2 atanf, 3
-// atan2f(y = the argument, x = the float with bit pattern x_bits) -- on the device in chunks of 2^24 and through std::sin / cos /
-// atan / atan2 on `threads` host threads; NaN results compare equal whatever their payload.  All of sinf takes about a minute.
-NB_EXPORT int nb_selftest_libm(int fn, uint32_t first, uint64_t count, uint32_t x_bits, uint64_t *mismatches, uint32_t *first_bad)
-{
-    if (!mismatches || fn < 0 || fn > 3 || count > (1ull << 32) || (uint64_t)first + count > (1ull << 32)) {
-        g_tls_error = "nb_selftest_libm: need mismatches != NULL, fn in 0..3 and first + count <= 2^32";
-        return NB_ERR_INVALID;
-    }
-    if (count == 0 && first == 0) count = 1ull << 32;
-    int rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    constexpr uint32_t kChunk = 1u << 24;
-    uint32_t *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_out, (size_t)kChunk * sizeof(uint32_t));
-    std::vector<uint32_t> got(kChunk);
-    const unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::atomic<uint64_t> bad{0};
-    std::atomic<uint64_t> where{~0ull};
-    float xo;
-    std::memcpy(&xo, &x_bits, 4);
-    for (uint64_t done = 0; done < count && e == hipSuccess; done += kChunk) {
-        const uint32_t base = (uint32_t)(first + done), m = (uint32_t)std::min<uint64_t>(kChunk, count - done);
-        e = nbk::launch_libm_selftest(fn, base, m, x_bits, d_out, nullptr);
-        if (e == hipSuccess) e = hipMemcpy(got.data(), d_out, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) break;
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t)
-            pool.emplace_back([&, t] {
-                uint64_t mine = 0;
-                for (uint32_t i = t; i < m; i += threads) {
-                    const uint32_t u = base + i;
-                    float x, r;
-                    std::memcpy(&x, &u, 4);
-                    r = fn == 0 ? std::sin(x) : fn == 1 ? std::cos(x) : fn == 2 ? std::atan(x) : std::atan2(x, xo);
-                    uint32_t rb;
-                    std::memcpy(&rb, &r, 4);
-                    float g;
-                    std::memcpy(&g, &got[i], 4);
-                    if (rb != got[i] && !(r != r && g != g)) {
-                        ++mine;
-                        uint64_t cur = where.load();
-                        while ((uint64_t)u < cur && !where.compare_exchange_weak(cur, (uint64_t)u)) {
-                        }
-                    }
-                }
-                bad += mine;
-            });
-        for (auto &th : pool) th.join();
-    }
-    if (d_out) (void)hipFree(d_out);
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_selftest_libm: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    *mismatches = bad.load();
-    if (first_bad) *first_bad = where.load() == ~0ull ? 0u : (uint32_t)where.load();
-    return NB_OK;
-}
-
-NB_EXPORT int nb_selftest_rcp_scaling(int k_lo, int k_hi, uint64_t *violations)
-{
-    if (!violations || k_lo > k_hi || k_lo < -125 || k_hi > 125) {
-        g_tls_error = "nb_selftest_rcp_scaling: need violations != NULL and -125 <= k_lo <= k_hi <= 125";
-        return NB_ERR_INVALID;
-    }
-    int rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    unsigned long long *d_bad = nullptr;
-    hipError_t e = hipMalloc((void **)&d_bad, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = nbk::launch_rcp_scaling(k_lo, k_hi, d_bad, nullptr);
-    unsigned long long bad = 0;
-    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
-    if (d_bad) (void)hipFree(d_bad);
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_selftest_rcp_scaling: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    *violations = bad;
-    return NB_OK;
-}
-
-namespace {
-// The clock a kernel ran at, from the (s_memtime, s_memrealtime) stamps its workgroups' first waves left at entry and exit
-// (4 words per workgroup): median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz -- s_memrealtime ticks at a
-// constant 100 MHz, s_memtime at the shader clock (MI355X_MICROARCH.md, "DVFS give-back" (6)).  Also the median lifetime of
-// those waves in shader cycles.  Workgroups too short to time (< 20 us) are left out.
-bool clock_from_stamps(const std::vector<unsigned long long> &st, double *mhz, double *cycles)
-{
-    std::vector<double> f, c;
-    for (size_t i = 0; i + 3 < st.size(); i += 4) {
-        const unsigned long long t0 = st[i], r0 = st[i + 1], t1 = st[i + 2], r1 = st[i + 3];
-        if (r1 <= r0 + 2000ull || t1 <= t0) continue;
-        f.push_back((double)(t1 - t0) / (double)(r1 - r0) * 100.0);
-        c.push_back((double)(t1 - t0));
-    }
-    if (f.empty()) return false;
-    std::sort(f.begin(), f.end());
-    std::sort(c.begin(), c.end());
-    *mhz = f[f.size() / 2];
-    *cycles = c[c.size() / 2];
-    return true;
-}
-}  // namespace
-
-NB_EXPORT int nb_selftest_valu_rate(int mix, double seconds, double *lane_ops_per_s, double *clock_mhz)
-{
-    if (!lane_ops_per_s || !(seconds > 0.0) || seconds > 2.0 || (mix < 0 || mix > 4)) {
-        g_tls_error = "nb_selftest_valu_rate: need lane_ops_per_s != NULL, mix 0 .. 4 and 0 < seconds <= 2";
-        return NB_ERR_INVALID;
-    }
-    int rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    float *sink = nullptr;
-    unsigned long long *stamps = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const uint32_t blocks = (uint32_t)cus * 8u;  // 256 lanes = one wave per SIMD each: 8 waves per SIMD
-    if (e == hipSuccess) e = hipMalloc((void **)&sink, 64);
-    if (e == hipSuccess && clock_mhz) e = hipMalloc((void **)&stamps, (size_t)blocks * 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    auto timed = [&](uint32_t trips, float *ms) {
-        hipError_t x = hipEventRecord(e0, nullptr);
-        if (x == hipSuccess) x = nbk::launch_valu_stream(mix, blocks, trips, sink, stamps, nullptr);
-        if (x == hipSuccess) x = hipEventRecord(e1, nullptr);
-        if (x == hipSuccess) x = hipEventSynchronize(e1);
-        if (x == hipSuccess) x = hipEventElapsedTime(ms, e0, e1);
-        return x;
-    };
-    float ms = 0.f;
-    uint32_t trips = 2000;
-    if (e == hipSuccess) e = timed(trips, &ms);  // warm-up + calibration (~ 1 ms)
-    if (e == hipSuccess && ms > 0.f) {
-        const double want = seconds * 1e3 / (double)ms * (double)trips;
-        trips = (uint32_t)std::min(std::max(want, 1000.0), 4.0e8);
-        e = timed(trips, &ms);
-    }
-    if (e == hipSuccess && clock_mhz) {
-        std::vector<unsigned long long> st((size_t)blocks * 4);
-        e = hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double cycles = 0.0;
-        if (e == hipSuccess && !clock_from_stamps(st, clock_mhz, &cycles)) *clock_mhz = 0.0;
-    }
-    if (sink) (void)hipFree(sink);
-    if (stamps) (void)hipFree(stamps);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (e != hipSuccess || !(ms > 0.f)) {
-        g_tls_error = std::string("nb_selftest_valu_rate: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    // 64 instructions per trip and lane; a packed instruction (mix 2) is two lane operations
-    *lane_ops_per_s = (mix == 2 ? 128.0 : 64.0) * (double)trips * 256.0 * (double)blocks / ((double)ms * 1e-3);
-    return NB_OK;
-}
-
-// The clock the part holds under the whole-set step kernel of `params` (step_strict_kernel / step_fast_wave_kernel) on n
-// bodies of the reference's initial distribution: back-to-back steps for about `seconds`, the last one stamped.
-NB_EXPORT int nb_diag_step_clock(const nb_params *params, uint32_t n, double seconds, double *clock_mhz, double *wave_cycles,
-                                 double *kernel_ms)
-{
-    if (!clock_mhz || !(seconds > 0.0) || seconds > 5.0 || n == 0) {
-        g_tls_error = "nb_diag_step_clock: need clock_mhz != NULL, n > 0 and 0 < seconds <= 5";
-        return NB_ERR_INVALID;
-    }
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    Plan pl;
-    int rc = make_plan(p, n, n, &pl, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    if ((p.mode == NB_MODE_STRICT && (pl.bc || pl.pc || pl.lanes != 1)) || (p.mode == NB_MODE_FAST && !pl.waves && !pl.pairs)) {
-        g_tls_error = "nb_diag_step_clock: only the whole-set kernels carry stamps (STRICT one lane per body, FAST wave and pairs forms)";
-        return NB_ERR_UNSUPPORTED;
-    }
-    nb_ctx *c = nullptr;
-    rc = nb_create(n, 1, &p, &c);
-    if (rc != NB_OK) return rc;
-    std::vector<float> pos((size_t)n * 3), vel((size_t)n * 3);
-    nb_init_state(1234, n, pos.data(), vel.data());
-    rc = nb_upload(c, pos.data(), vel.data());
-    const uint32_t bodies = p.mode == NB_MODE_STRICT ? (pl.sl == 3u ? 64u : 256u) : 64u * pl.ib;
-    size_t groups = (size_t)((n + bodies - 1u) / bodies) * (p.mode == NB_MODE_FAST ? pl.slices : 1u);
-    if (p.mode == NB_MODE_FAST && pl.pairs) {  // one workgroup per superblock pair
-        const size_t ns = nbk::fast_pairs_rows(n, pl.pairs, pl.pairs_np);
-        groups = std::max<size_t>(1, ns * (ns - 1) / 2);
-    }
-    unsigned long long *stamps = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipSuccess;
-    float ms = 0.f;
-    if (rc == NB_OK) {
-        e = hipMalloc((void **)&stamps, groups * 4 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemsetAsync(stamps, 0, groups * 4 * sizeof(unsigned long long), c->stream);
-        if (e == hipSuccess) e = hipEventCreate(&e0);
-        if (e == hipSuccess) e = hipEventCreate(&e1);
-        // calibrate on two steps, then fill `seconds`
-        if (e == hipSuccess) rc = nb_step(c, 1);
-        if (e == hipSuccess && rc == NB_OK) e = hipEventRecord(e0, c->stream);
-        if (e == hipSuccess && rc == NB_OK) rc = nb_step(c, 1);
-        if (e == hipSuccess && rc == NB_OK) e = hipEventRecord(e1, c->stream);
-        if (e == hipSuccess && rc == NB_OK) e = hipEventSynchronize(e1);
-        if (e == hipSuccess && rc == NB_OK) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e == hipSuccess && rc == NB_OK && ms > 0.f) {
-            const uint32_t k = (uint32_t)std::min(std::max(seconds * 1e3 / (double)ms, 2.0), 100000.0);
-            rc = nb_step(c, k - 1u);
-            // the stamped step: the same launch with StepArgs::stamps set
-            if (rc == NB_OK) e = hipEventRecord(e0, c->stream);
-            if (rc == NB_OK && e == hipSuccess) {
-                nbk::StepArgs a{};
-                a.pos_in = c->pos[c->cur];
-                a.pos_out = c->pos[c->cur ^ 1];
-                a.vel = c->vel;
-                a.partial = (float4 *)c->scratch;
-                a.n_total = a.count = a.j_count = n;
-                a.dt = p.dt;
-                a.G = p.G;
-                a.bias = p.bias;
-                a.lo_bits = pl.lo_bits;
-                a.hi_bits = pl.hi_bits;
-                a.force_ieee = pl.force_ieee;
-                a.force_3d = pl.force_3d;
-                a.j_chunk = pl.j_chunk;
-                a.no_packed = pl.no_packed;
-                a.hole_lo = 0xffffffffu;
-                a.stamps = stamps;
-                e = p.mode == NB_MODE_STRICT ? (pl.sl ? nbk::launch_strict_sl(a, pl.sl - 1u, c->scratch, c->stream)
-                                                      : nbk::launch_strict(a, pl.tile, pl.unroll, pl.lanes, c->stream))
-                                             : pl.pairs ? nbk::launch_fast_pairs(a, pl.pairs, pl.pairs_np, pl.pairs_chunk, c->scratch, c->stream)
-                                             : pl.fsl ? nbk::launch_fast_sl(a, pl.ib, pl.slices, c->scratch, c->stream)
-                                                      : nbk::launch_fast_wave(a, pl.tile, pl.ib, pl.waves, pl.slices, c->stream);
-            }
-            if (rc == NB_OK && e == hipSuccess) e = hipEventRecord(e1, c->stream);
-            if (rc == NB_OK && e == hipSuccess) e = hipEventSynchronize(e1);
-            if (rc == NB_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        }
-    }
-    double mhz = 0.0, cycles = 0.0;
-    if (rc == NB_OK && e == hipSuccess) {
-        std::vector<unsigned long long> st(groups * 4);
-        e = hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && !clock_from_stamps(st, &mhz, &cycles)) {
-            g_tls_error = "nb_diag_step_clock: no workgroup ran long enough to time";
-            rc = NB_ERR_STATE;
-        }
-    }
-    if (rc != NB_OK && c) g_tls_error = c->err.empty() ? g_tls_error : c->err;
-    if (stamps) (void)hipFree(stamps);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    nb_destroy(c);
-    if (rc != NB_OK) return rc;
-    if (e != hipSuccess) {
-        g_tls_error = std::string("nb_diag_step_clock: ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    *clock_mhz = mhz;
-    if (wave_cycles) *wave_cycles = cycles;
-    if (kernel_ms) *kernel_ms = (double)ms;
-    return NB_OK;
-}
+#include "nb_selftest.inc"
 
 // ---- launch API -----------------------------------------------------------------------------------------
 
@@ -2356,275 +1620,8 @@ NB_EXPORT int nb_launch_step_phase(const nb_params *params, uint32_t n_total, ui
     return launch_phase_planned(p, pp, n_total, first, count, j_lo, phase, pos_in, pos_out, vel, scratch, (hipStream_t)stream, &g_tls_error);
 }
 
-// ---- FAST on shards, every unordered pair once ("half shell", nb_nbody_ring.inc) ------------------------------------------
-namespace {
-constexpr uint64_t kRingMinPairs = 1ull << 30;  // ordered pairs of a rank's step from which the form is taken by itself
-struct RingPlan {
-    Plan base;      // the sharing verdict (force_ieee), force_3d
-    uint32_t np;    // packed pairs of bodies per lane: 4 (blocks of 512) where the shard is whole blocks of 512, else 2 (256)
-    uint32_t ga, wpb;
-    uint32_t partners;  // 0: this shape does not take the form
-    uint32_t c4_own, c4_rest, cap;  // the step in phases: sub-tiles per workgroup, sub-tiles of a block's own part in the first phase (0: the kernels' defaults)
-    bool phased;        // the shape can run its step in phases (nb_launch_ring_fold_phase)
-    size_t scratch_floats;  // rows behind the planes area: the most ANY rank of the job needs (a host may size one buffer for all)
-};
-// Which shards take the form by themselves: FAST, at least two equal ranks of whole blocks, and enough pairs per rank that what
-// the form saves pays for its second exchange: against the ordered fold of the same shard it saves n_total x count / 3e7 us
-// (profiles/r04/ring_times.log, ring_small.log: 15 us at 65 536 x 8 192, 26 at 65 536 x 16 384, 73 at 131 072 x 16 384; nothing at
-// 32 768 bodies on 4 or 8 ranks), the second exchange costs 17-23 us on a communicator of one (profiles/r04/step_overhead.log):
-// the line is n_total x count >= 2^30.  NB_RING=0/1 decides outright where the shape allows it; NB_RING_NP / NB_RING_GA /
-// NB_RING_WPB name the kernel's shape (tests, tools/).
-int make_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, RingPlan *out, std::string *err)
-{
-    int rc = make_plan(p, n_total, count, &out->base, err);
-    if (rc != NB_OK) return rc;
-    const DebugOverrides &dbg = overrides();
-    out->partners = 0;
-    out->np = (count % 512u == 0u) ? 4u : 2u;
-    if (dbg.ring_np.set && (dbg.ring_np.v == 2u || dbg.ring_np.v == 4u)) out->np = dbg.ring_np.v;
-    out->ga = dbg.ring_ga.or_else(0u);
-    out->wpb = dbg.ring_wpb.or_else(0u) & ~3u;
-    out->c4_own = dbg.ring_c4_own.or_else(0u);
-    out->c4_rest = dbg.ring_c4_rest.or_else(0u);
-    out->cap = dbg.ring_cap.or_else(0u);
-    out->phased = false;
-    out->scratch_floats = 0;
-    if (p.mode != NB_MODE_FAST || (uint64_t)first + count > n_total) return NB_OK;
-    if (!dbg.ring.or_else((uint64_t)n_total * count >= kRingMinPairs ? 1u : 0u)) return NB_OK;
-    out->partners = nbk::ring_partners(n_total, first, count, out->np);
-    // the rows: the phases' layout differs a little from rank to rank (the lists of the upper half of the ring are a block shorter), so
-    // the size is the largest of all ranks' -- every rank of a job gets the same answer, as before the phases existed
-    if (out->partners)
-        for (uint32_t f = 0; (uint64_t)f + count <= n_total; f += count)
-            out->scratch_floats = std::max(out->scratch_floats, nbk::ring_scratch_floats(n_total, f, count, out->np, out->ga, out->wpb, out->c4_own, out->c4_rest, out->cap));
-    // (the phases' shape is searched for ONCE, here: c4_own / c4_rest / cap leave resolved, and every launch of the plan names them)
-    out->phased = out->partners != 0u && nbk::ring_phased(n_total, first, count, out->np, out->ga, out->wpb, &out->c4_own, &out->c4_rest, &out->cap);
-    return NB_OK;
-}
-size_t ring_scratch_bytes(const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count)
-{
-    return nbk::strict_bc_scratch_bytes(n_total) + rp.scratch_floats * sizeof(float);
-}
-int cached_ring_plan(const nb_params &p, uint32_t n_total, uint32_t first, uint32_t count, const RingPlan **out, std::string *err)
-{
-    struct Entry {
-        bool valid = false;
-        nb_params p{};
-        uint32_t n_total = 0, first = 0, count = 0, generation = 0;
-        RingPlan rp{};
-    };
-    constexpr int kEntries = 2;
-    thread_local Entry cache[kEntries];
-    thread_local int next = 0;
-    const uint32_t gen = overrides().generation;
-    for (int i = 0; i < kEntries; ++i) {
-        const Entry &e = cache[i];
-        if (e.valid && e.n_total == n_total && e.first == first && e.count == count && e.generation == gen && std::memcmp(&e.p, &p, sizeof(p)) == 0) {
-            *out = &e.rp;
-            return NB_OK;
-        }
-    }
-    RingPlan rp;
-    int rc = make_ring_plan(p, n_total, first, count, &rp, err);
-    if (rc != NB_OK) return rc;
-    Entry &e = cache[next];
-    next = (next + 1) % kEntries;
-    e.valid = true;
-    e.p = p;
-    e.n_total = n_total;
-    e.first = first;
-    e.count = count;
-    e.generation = gen;
-    e.rp = rp;
-    *out = &e.rp;
-    return NB_OK;
-}
-nbk::StepArgs ring_step_args(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
-                             void *pos_out, void *vel)
-{
-    nbk::StepArgs a{};
-    a.pos_in = (const float4 *)pos_in;
-    a.pos_out = (float4 *)pos_out;
-    a.vel = (float4 *)vel;
-    a.n_total = n_total;
-    a.first = first;
-    a.count = count;
-    a.dt = p.dt;
-    a.G = p.G;
-    a.bias = p.bias;
-    a.force_ieee = rp.base.force_ieee;
-    a.force_3d = rp.base.force_3d;
-    return a;
-}
-int launch_ring_fold_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
-                             void *sums, void *scratch, hipStream_t stream, std::string *err)
-{
-    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, nullptr, nullptr);
-    hipError_t e = nbk::launch_fast_ring(a, rp.np, rp.ga, rp.wpb, scratch, (float4 *)sums, stream);
-    if (e != hipSuccess) {
-        *err = std::string("nb: kernel launch failed (ring fold): ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    return NB_OK;
-}
-int launch_ring_phase_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
-                              void *sums, void *scratch, hipStream_t stream, std::string *err)
-{
-    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, nullptr, nullptr);
-    hipError_t e = nbk::launch_fast_ring_phase(a, rp.np, rp.ga, rp.wpb, rp.c4_own, rp.c4_rest, rp.cap, (uint32_t)phase, scratch, (float4 *)sums, stream);
-    if (e != hipSuccess) {
-        *err = std::string("nb: kernel launch failed (ring fold, phase ") + std::to_string(phase) + "): " + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    return NB_OK;
-}
-int launch_ring_finish_planned(const nb_params &p, const RingPlan &rp, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
-                               void *pos_out, void *vel, const void *sums, const void *recv, hipStream_t stream, std::string *err)
-{
-    const nbk::StepArgs a = ring_step_args(p, rp, n_total, first, count, pos_in, pos_out, vel);
-    hipError_t e = nbk::launch_ring_finish(a, (const float4 *)sums, (const float4 *)recv, rp.partners, stream);
-    if (e != hipSuccess) {
-        *err = std::string("nb: kernel launch failed (ring finish): ") + hipGetErrorString(e);
-        return NB_ERR_HIP;
-    }
-    return NB_OK;
-}
-}  // namespace
+#include "nb_ring_api.inc"
 
-NB_EXPORT int nb_ring_partners(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    const RingPlan *rp = nullptr;
-    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    return (int)rp->partners;
-}
-
-NB_EXPORT size_t nb_ring_scratch_bytes(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    RingPlan rp;
-    std::string err;
-    if (make_ring_plan(p, n_total, first, count, &rp, &err) != NB_OK || rp.partners == 0u) return 0;
-    return ring_scratch_bytes(rp, n_total, first, count);
-}
-
-NB_EXPORT int nb_launch_ring_fold(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *sums,
-                                  void *scratch, size_t scratch_bytes, void *stream)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    if (!pos_in || !sums || !scratch) {
-        g_tls_error = "nb_launch_ring_fold: pos_in, sums and scratch must be non-null";
-        return NB_ERR_INVALID;
-    }
-    const RingPlan *rp = nullptr;
-    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (rp->partners == 0u) {
-        g_tls_error = "nb_launch_ring_fold: this shape does not take the pairs form on shards (nb_ring_partners() == 0): use nb_launch_step";
-        return NB_ERR_UNSUPPORTED;
-    }
-    if (scratch_bytes < ring_scratch_bytes(*rp, n_total, first, count)) {
-        g_tls_error = "nb_launch_ring_fold: scratch smaller than nb_ring_scratch_bytes()";
-        return NB_ERR_INVALID;
-    }
-    rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (!stream) {
-        rc = select_device_of(pos_in, &g_tls_error);
-        if (rc != NB_OK) return rc;
-    }
-    return launch_ring_fold_planned(p, *rp, n_total, first, count, pos_in, sums, scratch, (hipStream_t)stream, &g_tls_error);
-}
-
-NB_EXPORT int nb_ring_phased(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    const RingPlan *rp = nullptr;
-    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    return rp->phased ? 1 : 0;
-}
-
-NB_EXPORT int nb_launch_ring_fold_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
-                                        void *sums, void *scratch, size_t scratch_bytes, void *stream)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    if (!pos_in || !sums || !scratch) {
-        g_tls_error = "nb_launch_ring_fold_phase: pos_in, sums and scratch must be non-null";
-        return NB_ERR_INVALID;
-    }
-    if (phase < NB_RING_OWN || phase > NB_RING_SUMS) {
-        g_tls_error = "nb_launch_ring_fold_phase: phase must be NB_RING_OWN, NB_RING_REST or NB_RING_SUMS";
-        return NB_ERR_INVALID;
-    }
-    const RingPlan *rp = nullptr;
-    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (!rp->phased) {
-        g_tls_error = "nb_launch_ring_fold_phase: this shape does not run its step in phases (nb_ring_phased() == 0): use nb_launch_ring_fold";
-        return NB_ERR_UNSUPPORTED;
-    }
-    if (scratch_bytes < ring_scratch_bytes(*rp, n_total, first, count)) {
-        g_tls_error = "nb_launch_ring_fold_phase: scratch smaller than nb_ring_scratch_bytes()";
-        return NB_ERR_INVALID;
-    }
-    rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (!stream) {
-        rc = select_device_of(pos_in, &g_tls_error);
-        if (rc != NB_OK) return rc;
-    }
-    return launch_ring_phase_planned(p, *rp, n_total, first, count, phase, pos_in, sums, scratch, (hipStream_t)stream, &g_tls_error);
-}
-
-NB_EXPORT int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in,
-                                    void *pos_out, void *vel, const void *sums, const void *recv, void *stream)
-{
-    nb_params p;
-    if (params)
-        p = *params;
-    else
-        nb_default_params(&p);
-    if (!pos_in || !pos_out || !vel || !sums || !recv || pos_in == pos_out) {
-        g_tls_error = "nb_launch_ring_finish: pos_in, pos_out, vel, sums, recv must be non-null and pos_out must not alias pos_in";
-        return NB_ERR_INVALID;
-    }
-    const RingPlan *rp = nullptr;
-    int rc = cached_ring_plan(p, n_total, first, count, &rp, &g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (rp->partners == 0u) {
-        g_tls_error = "nb_launch_ring_finish: this shape does not take the pairs form on shards (nb_ring_partners() == 0)";
-        return NB_ERR_UNSUPPORTED;
-    }
-    rc = check_device(&g_tls_error);
-    if (rc != NB_OK) return rc;
-    if (!stream) {
-        rc = select_device_of(pos_in, &g_tls_error);
-        if (rc != NB_OK) return rc;
-    }
-    return launch_ring_finish_planned(p, *rp, n_total, first, count, pos_in, pos_out, vel, sums, recv, (hipStream_t)stream, &g_tls_error);
-}
 
 // 1: this library holds every launch shape the diagnostic knobs can name (built with -DNB_LEGACY_FORMS: make legacy); 0: the product
 // build, which holds the shapes make_plan reaches by itself
