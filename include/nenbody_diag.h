@@ -87,6 +87,10 @@ int nb_diag_rccl_solo(int on);
  * workgroup-tile FAST form, wave counts other than eight, ...). */
 int nb_diag_legacy_forms(void);
 
+/* on != 0: rank 0's pulls over xGMI (nb_peers_gather / nb_peers_ring) lose their first record -- what a peer's stores not being visible
+ * when its flag says so would look like.  A process switch for the test suite: the fallbacks of verify_exchanges on a one-GPU box. */
+int nb_diag_peers_lossy(int on);
+
 /* The kernels one step of this shape launches, dominant one first, comma separated ("step_strict_bc_kernel,planes_kernel"),
  * as the library itself plans the launch (make_plan): what bench.py labels its roofline with. */
 int nb_diag_plan(const nb_params *params, uint32_t n_total, uint32_t count, char *out, size_t out_bytes);

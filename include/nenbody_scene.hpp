@@ -158,7 +158,7 @@ public:
     struct ExchangePaths {
         int gather, ring;
     };
-    ExchangePaths verify_exchanges()
+    ExchangePaths verify_exchanges()  // (gather 2 / ring 3: pulled over xGMI, see peer_import)
     {
         ExchangePaths p{0, -1};
         check_sh(nb_shard_verify_exchanges(sh_, &p.gather, &p.ring));

@@ -176,6 +176,7 @@ DIAG_PROTOTYPES = {
     "nb_diag_enable_env": (c_int, [c_int]),
     "nb_diag_rccl_solo": (c_int, [c_int]),
     "nb_diag_legacy_forms": (c_int, []),
+    "nb_diag_peers_lossy": (c_int, [c_int]),
     "nb_diag_plan": (c_int, [POINTER(NbParams), c_uint32, c_uint32, ctypes.c_char_p, c_size_t]),
 }
 

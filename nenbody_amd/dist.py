@@ -832,8 +832,8 @@ class NativeShard:
 
     def verify_exchanges(self):
         """both exchanges once on a known pattern, checked on every rank (``nb_shard_verify_exchanges``; collective): returns
-        (gather_path, ring_path) -- 0 / 1: in place / from a copy; -1 / 0 / 1 / 2: no pairs form / one group / one group per
-        distance / dropped for the ordered fold"""
+        (gather_path, ring_path) -- 0 / 1 / 2: in place / from a copy / pulled over xGMI; -1 / 0 / 1 / 2 / 3: no pairs form / one group /
+        one group per distance / dropped for the ordered fold / pulled over xGMI"""
         g, r = ctypes.c_int(), ctypes.c_int()
         self._check(self._lib.nb_shard_verify_exchanges(self._sh, ctypes.byref(g), ctypes.byref(r)))
         return g.value, r.value

@@ -213,8 +213,14 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
                                      gather=None if peers == "only" else gather, overlap=overlap, ring=ring if (with_ring and peers != "only") else None,
                                      peers=swap_blobs if peers else None) as sh:
             extra = {}
-            if verify == "verify_only":   # the pattern through whatever exchange the shard uses; the form stays the one asked for
-                assert sh.verify_exchanges() == (0, 0 if sh.partners else -1)
+            if verify == "lossy_pulls":   # pulls that lose a record on rank 0: every rank goes back to the host's exchanges, in both
+                nenbody_amd.load().nb_diag_peers_lossy(1)
+                try:
+                    assert sh.verify_exchanges() == (0, 0 if sh.partners else -1)
+                finally:
+                    nenbody_amd.load().nb_diag_peers_lossy(0)
+            elif verify == "verify_only":   # the pattern through whatever exchange the shard uses; the form stays the one asked for
+                assert sh.verify_exchanges() == ((2, 3 if sh.partners else -1) if peers else (0, 0 if sh.partners else -1))
                 assert sh.pairs_overlapped == bool(overlap and sh.partners)
             elif verify:   # both exchanges on a known pattern first, then the machine is asked which form to take
                 before = sh.partners
@@ -393,6 +399,29 @@ def test_shards_that_pull_their_exchanges_over_ipc(tmp_path, nb, oracle, world, 
             assert np.quantile(dv, 0.999) <= 2e-4 * scale and dv.max() <= 2e-2 * scale, f"rank {r}: {np.quantile(dv, 0.999) / scale:.2e} {dv.max() / scale:.2e}"
             dp = np.abs(got["pos"] - p_ref).max(axis=1)
             assert np.quantile(dp, 0.999) <= 4e-4 * scale and dp.max() <= 4e-2 * scale, f"rank {r} positions (replica)"
+
+
+def test_pulls_that_lose_data_send_both_exchanges_back_to_the_hosts(tmp_path, nb, oracle):
+    """nb_shard_verify_exchanges on a shard that pulls its exchanges over IPC, with rank 0's pulls made lossy (nb_diag_peers_lossy: the
+    first record of what it pulls is overwritten -- what stores that are not visible when their flag says so would look like): every
+    rank must see the verdict and go back to the exchanges chosen before (here the host's gather and ring functions), and the steps
+    that follow run through those and are right."""
+    import torch.multiprocessing as mp
+
+    world, n, schedule = 4, 32768, (("nbody", 3),)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(tmp_path), False, schedule, True, 77, True, "lossy_pulls", True), nprocs=world, join=True)
+    pos, vel = oracle.init_state(n, 77)
+    p_ref, v_ref = reference(oracle, pos, vel, schedule)
+    scale = float(np.abs(v_ref - vel).max())
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        first, count = int(got["first"]), int(got["count"])
+        assert int(got["partners"]) == 2 and int(got["ring_calls"]) >= 3 and int(got["calls"]) >= 3      # the host's exchanges carried the steps
+        dv = np.abs(got["vel"] - v_ref[first:first + count]).max(axis=1)
+        assert np.quantile(dv, 0.999) <= 1e-4 * scale and dv.max() <= 1e-2 * scale, f"rank {r}"
 
 
 def test_native_shard_boids_split_form(nb, oracle):
