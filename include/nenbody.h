@@ -338,9 +338,10 @@ void nb_peers_destroy(nb_peers *p);
 const char *nb_peers_last_error(const nb_peers *p);
 int nb_peers_export(nb_peers *p, void *const *bufs, const size_t *bytes, int nbufs, void *blob);
 int nb_peers_import(nb_peers *p, const void *blobs /* world x nb_peers_blob_bytes(), rank-major */);
-/* First contact with a deadline (collective): a signal / wait / one-record pull round on a stream of its own, watched by the host for
- * at most timeout_ms.  NB_ERR_STATE: some peer's word never became visible -- that stream alone stays blocked and is abandoned; keep
- * the collectives.  Hosts call it once after nb_peers_import (ShardedScene.setup_peers and nb_shard_peer_import do). */
+/* First contact with a deadline (collective), in two stages: this rank signals and the HOST reads every peer's word through the mapping
+ * until it shows the signal or timeout_ms has passed (nothing can block); only then a wait / one-record pull round on a stream of its
+ * own, watched for the same time (a wait the command processor cannot satisfy is released by hand).  NB_ERR_STATE: keep the collectives.
+ * Hosts call it once after nb_peers_import (ShardedScene.setup_peers and nb_shard_peer_import do). */
 int nb_peers_probe(nb_peers *p, uint32_t timeout_ms);
 int nb_peers_signal(nb_peers *p, int channel, void *stream);
 int nb_peers_gather(nb_peers *p, int channel, int buf, size_t slot_bytes, void *stream);
