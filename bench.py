@@ -247,8 +247,10 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
     # kernel-only timing: events on the stream the kernels are launched on (torch's current stream), around every launch call of
     # a step (one: nb_launch_step; the pairs form on shards: nb_launch_ring_fold and nb_launch_ring_finish -- or the three phases --
     # the exchanges between them outside the events)
-    calls = (("ring_fold_phase", "ring_finish") if sc.ring_overlap else ("ring_fold", "ring_finish")) if sc.partners else ("step",)
-    per_step = (4 if sc.ring_overlap else 2) if sc.partners else 1
+    # (in phases: OWN / REST / SUMS / the fused finish; pulls run in-stream, nothing runs beside them: the finish adds the own records itself)
+    calls = (("ring_fold_phase", "ring_finish_phase") if sc.ring_overlap else ("ring_fold", "ring_finish")) if sc.partners else ("step",)
+    sums_in_finish = sc.exchange == "peers" and bool(getattr(sc, "_peers_sums", None))
+    per_step = ((3 if sums_in_finish else 4) if sc.ring_overlap else 2) if sc.partners else 1
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * per_step)]
     real = {name: getattr(sc.backend, name) for name in calls}
     used = [0]
@@ -279,7 +281,8 @@ def time_mode(nb, torch, dist, args, mode, rank, world, pos, vel, steps=None, wa
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     # (the overlapped ORDERED form launches its two phases through step_phase: no per-kernel events there, wall time only)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps if sc.count and used[0] == len(ev) else 0.0
-    kernels = (["step_fast_ring_kernel", "planes_kernel" if not sc.ring_overlap else "ring_planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"] if sc.partners
+    kernels = ((["step_fast_ring_kernel", "ring_planes_kernel", "ring_reduce_kernel", "ring_finish_phase_kernel"] if sc.ring_overlap
+                else ["step_fast_ring_kernel", "planes_kernel", "ring_reduce_kernel", "ring_finish_kernel"]) if sc.partners
                else step_kernels(nb, mode, sc.n, sc.count))
     each = [sum(a.elapsed_time(b) for a, b in ev[i * per_step:(i + 1) * per_step]) for i in range(steps)] if sc.count and used[0] == len(ev) else []
     out = {"elapsed_s": float(elapsed.item()), "kernel_ms": kern_ms, "kernel_ms_each": each, "count": sc.count, "n": sc.n, "steps": steps, "preheat_steps": pre,

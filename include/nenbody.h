@@ -269,10 +269,23 @@ int nb_launch_ring_finish(const nb_params *params, uint32_t n_total, uint32_t fi
  * nb_ring_phased: 1 where the shape can run its step this way (nb_ring_partners() > 0 and the rank's rows fit one launch -- every
  * rank count of BASELINE's config 4; config 5's ranks walk their rows in groups and keep nb_launch_ring_fold: two exchanges of
  * 2 MB per peer against 13.6 ms of compute), 0 where it keeps nb_launch_ring_fold; or a negative nb_status. */
-enum { NB_RING_OWN = 1, NB_RING_REST = 2, NB_RING_SUMS = 3 };
+enum { NB_RING_OWN = 1, NB_RING_REST = 2, NB_RING_SUMS = 3, NB_RING_OWN_READY = 4 };
 int nb_ring_phased(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count);
 int nb_launch_ring_fold_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, int phase, const void *pos_in,
                               void *sums, void *scratch, size_t scratch_bytes, void *stream);
+/* The finish of a step in phases, FUSED (two launches fewer per step: every small launch of a step costs ~5 us of ramp and drain):
+ *   nb_launch_ring_finish_phase  with sums == NULL adds the rank's own records ITSELF -- NB_RING_SUMS is not launched; the same
+ *                                additions in the same order, the same bits -- (a host that runs NB_RING_SUMS beside its second
+ *                                exchange passes `sums`: records [0, count) are read instead); then the D received chunks and
+ *                                src/main.rs:434-436 as nb_launch_ring_finish; and leaves the planes and flag words of the NEW own
+ *                                slot (pos_out[first, first + count)) in `scratch`.
+ *   NB_RING_OWN_READY            NB_RING_OWN of the NEXT step without the launch that prepares its planes: valid when the last thing
+ *                                that touched `scratch` was nb_launch_ring_finish_phase of the same shape and this call's pos_in is
+ *                                that call's pos_out.  (pos_in is not read.)
+ *     step k:  OWN_READY | wait(all-gather k - 1) | REST | second exchange | finish_phase | [all-gather k] ...
+ * The first step of a run, and any step behind something else that used `scratch`, starts with NB_RING_OWN. */
+int nb_launch_ring_finish_phase(const nb_params *params, uint32_t n_total, uint32_t first, uint32_t count, const void *pos_in, void *pos_out,
+                                void *vel, const void *sums, const void *recv, void *scratch, size_t scratch_bytes, void *stream);
 
 /* One boids step (main.rs:443-526) for bodies [first, first+count) of a set of n_total:
  *   pos_in, vel_in    n_total records each: the snapshots old_positions / old_velocities (main.rs:459-460), read only

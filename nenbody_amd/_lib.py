@@ -29,7 +29,7 @@ NB_MODE_FAST = 1
 NB_PHASE_RANGE = 0
 NB_PHASE_REST = 1
 # phases of the pairs form on shards (nb_launch_ring_fold_phase)
-NB_RING_OWN, NB_RING_REST, NB_RING_SUMS = 1, 2, 3
+NB_RING_OWN, NB_RING_REST, NB_RING_SUMS, NB_RING_OWN_READY = 1, 2, 3, 4
 
 _STATUS_NAMES = {
     NB_ERR_INVALID: "NB_ERR_INVALID",
@@ -123,6 +123,8 @@ PROTOTYPES = {
     "nb_launch_ring_fold_phase": (c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nb_launch_ring_finish": (
         c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nb_launch_ring_finish_phase": (
+        c_int, [POINTER(NbParams), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nb_launch_status": (c_int, [c_void_p]),
     "nb_launch_instances": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nb_launch_pack": (c_int, [c_uint32, c_void_p, c_void_p, c_void_p]),

@@ -121,6 +121,14 @@ hipError_t launch_fast_ring(const StepArgs &a, uint32_t np, uint32_t ga, uint32_
 hipError_t launch_fast_ring_kernels(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, const uint32_t *flags, uint32_t generation,
                                     const float *px, const float *py, const float *pz, float *scratch, float4 *sums, hipStream_t s);  // the kernels alone (-DNBK_SL_TU)
 hipError_t launch_ring_finish(const StepArgs &a, const float4 *sums, const float4 *recv, uint32_t partners, hipStream_t s);
+// the phases' finish, fused: adds the rank's own records itself (what == 3 is not launched) and leaves the planes and flag words of the
+// new own slot in `scratch` for the next step's first phase, launched as what == 4 (= 1 without its planes launch)
+// (sums != NULL: what == 3 ran, its records are read instead)
+hipError_t launch_fast_ring_finish_phase(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap, void *scratch,
+                                         const float4 *sums, const float4 *recv, hipStream_t s);
+hipError_t launch_ring_finish_phase_kernel(const StepArgs &a, uint32_t np, uint32_t ga, uint32_t wpb, uint32_t c4_own, uint32_t c4_rest, uint32_t cap,
+                                           uint32_t *flags, float *px, float *py, float *pz, float *scratch, const float4 *sums, const float4 *recv,
+                                           uint32_t gen_next, hipStream_t s);  // the kernel alone (-DNBK_SL_TU)
 // the fixed-order combine of `rows` partial-sum rows + integrate (what launch_fast runs itself after a split whole-set fold)
 hipError_t launch_integrate_partials(const StepArgs &a, uint32_t rows, hipStream_t s);
 // device_libm: 0 = the angle, its sine and cosine as the host's libm computes them (nb_libm.h: bit-identical matrices), 1 = the device's own

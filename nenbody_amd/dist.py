@@ -116,6 +116,18 @@ class HipBackend:
             check(self.lib.nb_launch_ring_finish(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
                                                  vel.data_ptr(), sums.data_ptr(), recv.data_ptr(), stream))
 
+    def ring_finish_phase(self, params, n_total, first, count, pos_in, pos_out, vel, sums, recv, scratch) -> None:
+        """the finish of a step in phases, fused (``nb_launch_ring_finish_phase``): with ``sums`` None it adds the rank's own
+        records itself (NB_RING_SUMS is not launched); it leaves the planes of the new own slot in ``scratch``, so the next step
+        starts with NB_RING_OWN_READY"""
+        import torch
+
+        stream = torch.cuda.current_stream(pos_in.device).cuda_stream
+        with torch.cuda.device(pos_in.device):
+            check(self.lib.nb_launch_ring_finish_phase(ctypes.byref(params), n_total, first, count, pos_in.data_ptr(), pos_out.data_ptr(),
+                                                       vel.data_ptr(), sums.data_ptr() if sums is not None else None, recv.data_ptr(),
+                                                       scratch.data_ptr(), scratch.numel(), stream))
+
     def instances(self, count, pos, vel, inst) -> None:
         import torch
 
@@ -205,6 +217,7 @@ class ShardedScene:
             self.recv = torch.zeros((self.partners * self.count, 4), dtype=torch.float32, device=self.device)
         self.overlap = bool(overlap) and self.params.mode == _lib.NB_MODE_FAST and world > 1 and not self.partners
         self._pending = None     # the exchange in flight (overlap): a torch.distributed work handle, or None
+        self._own_ready = None   # the scratch area in which a fused finish left the planes of the own slot (phases of the pairs form)
         # The pairs form with its exchanges hidden (round 5; nb_launch_ring_fold_phase): a round's worth of the pairs inside the
         # rank's own slot of step k + 1 runs while step k's all-gather lands; the second exchange leaves as soon as the sums of the
         # ranks in front are final, and the rank's own sums are made beside it.  ring_overlap=None: overlap decides (True: where the
@@ -475,6 +488,7 @@ class ShardedScene:
         and counts with reassociated sums, for shards whose bodies alone cannot fill the chip; default: bit-identical."""
         torch = self.torch
         self._wait_pending()
+        self._own_ready = None
         bp = params if params is not None else _lib.default_boids_params()
         boids = self.backend.boids_step
         if split and self.count and hasattr(self.backend, "boids_step_split"):
@@ -520,16 +534,25 @@ class ShardedScene:
     # -- one step: local update, then the exchange ------------------------------------------------------
     def step(self) -> None:
         src, dst = self.pos[self.cur], self.pos[self.cur ^ 1]
+        # (did the fused finish of the step before leave the own slot's planes in THIS scratch area?  Every other form of a step, and
+        # whatever rewrites the positions, uses it its own way)
+        ready, self._own_ready = self._own_ready is not None and self._own_ready is self.scratch, None
         if self.partners and self.ring_overlap:
             # src's other slots may still be landing; this rank's own slot of src was written by its own last finish
+            # The finish is the fused one: it leaves the planes of the new own slot in the scratch area, so every step but the first of a
+            # run starts with its sweep.  Pulls run on this stream -- nothing could run beside them: the finish adds the rank's own records
+            # itself; a collective runs on the communicator's stream, and NB_RING_SUMS keeps running beside it.
             be, a = self.backend, (self.params, self.n, self.first, self.count)
-            be.ring_fold_phase(*a, _lib.NB_RING_OWN, src, self.sums, self.scratch)
+            be.ring_fold_phase(*a, _lib.NB_RING_OWN_READY if ready else _lib.NB_RING_OWN, src, self.sums, self.scratch)
             self._wait_pending()
             be.ring_fold_phase(*a, _lib.NB_RING_REST, src, self.sums, self.scratch)     # the sums of the ranks in front are final
             started = self._ring_exchange_start()
-            be.ring_fold_phase(*a, _lib.NB_RING_SUMS, src, self.sums, self.scratch)     # ... the rank's own beside the exchange
+            in_stream = self.exchange == "peers" and self._peers_sums
+            if not in_stream:
+                be.ring_fold_phase(*a, _lib.NB_RING_SUMS, src, self.sums, self.scratch)     # ... the rank's own beside the exchange
             self._ring_exchange_wait(started)
-            be.ring_finish(*a, src, dst, self.vel, self.sums, self.recv)
+            be.ring_finish_phase(*a, src, dst, self.vel, None if in_stream else self.sums, self.recv, self.scratch)
+            self._own_ready = self.scratch
             self._pending = self._all_gather_slots(dst, async_op=True)
         elif self.partners:
             self._wait_pending()
@@ -596,6 +619,7 @@ class ShardedScene:
             self.pos[1].copy_(saved[1])
             self.vel.copy_(saved[2])
             self.cur, self.steps_done, self.velfull_valid = saved[3], saved[4], saved[5]
+            self._own_ready = None
 
         names, times = list(cands), []
         for name in names:
@@ -656,6 +680,7 @@ class ShardedScene:
             self.pos[1].copy_(saved[1])
             self.vel.copy_(saved[2])
             self.cur, self.steps_done, self.velfull_valid = saved[3], saved[4], saved[5]
+            self._own_ready = None
         on_device = self.dist.get_backend(self.group) == "nccl"
         t = torch.tensor([times["collective"], times["peers"]], dtype=torch.float64, device=self.device if on_device else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)

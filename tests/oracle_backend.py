@@ -63,7 +63,7 @@ class OracleBackend:
         return -(-(count + hmax) // count) - 1
 
     def ring_scratch_bytes(self, params, n_total, first, count):
-        return 2 * count * 16    # the phases keep two rows of count records here between their calls
+        return 3 * count * 16    # the phases keep two rows of count records here between their calls, the fused finish a third
 
     # the step in PHASES (nb_launch_ring_fold_phase): 1 = pairs inside the rank's own slot (here: those of the first 70 % of its
     # bodies -- a part, as the library's one round of workgroups is), 2 = every other pair + the sums of the ranks in front, 3 = the
@@ -72,9 +72,15 @@ class OracleBackend:
     def ring_phased(self, params, n_total, first, count):
         return self.ring_partners(params, n_total, first, count) > 0
 
+    #    Phase 4 (NB_RING_OWN_READY) is phase 1 on the planes the fused finish of the step before left: here a third row of the
+    #    scratch area holds the own slot's new positions, and phase 4 reads THEM -- never pos_in.
     def ring_fold_phase(self, params, n_total, first, count, phase, pos_in, sums, scratch):
-        keep = scratch.view(torch.float32).reshape(2 * count, 4)
-        own_acc, rest_acc = keep[:count, :3].numpy(), keep[count:, :3].numpy()
+        keep = scratch.view(torch.float32)[:3 * count * 4].reshape(3 * count, 4)
+        own_acc, rest_acc, planes = keep[:count, :3].numpy(), keep[count:2 * count, :3].numpy(), keep[2 * count:, :3].numpy()
+        if phase == 4:
+            snap = torch.full((n_total, 4), float("nan"))
+            snap[first:first + count, :3] = torch.from_numpy(planes.copy())
+            pos_in, phase = snap, 1
         if phase == 3:
             sums[:count, :3] = torch.from_numpy(own_acc + rest_acc)
             sums[:count, 3] = 0
@@ -134,6 +140,15 @@ class OracleBackend:
         pos_out[first:first + count, :3] = torch.from_numpy(v + old[first:first + count])
         pos_out[first:first + count, 3] = 0
         vel[:count, :3] = torch.from_numpy(v)
+
+    # the fused finish: sums None -> phase 3's addition happens here; the new own slot is left in the scratch area for phase 4
+    def ring_finish_phase(self, params, n_total, first, count, pos_in, pos_out, vel, sums, recv, scratch):
+        keep = scratch.view(torch.float32)[:3 * count * 4].reshape(3 * count, 4)
+        if sums is None:
+            sums = torch.zeros((count, 4))
+            sums[:, :3] = torch.from_numpy(keep[:count, :3].numpy() + keep[count:2 * count, :3].numpy())
+        self.ring_finish(params, n_total, first, count, pos_in, pos_out, vel, sums, recv)
+        keep[2 * count:, :3] = pos_out[first:first + count, :3]
 
     def instances(self, count, pos, vel, inst):
         m = oracle.instances(pos[:count, :3].contiguous().numpy(), vel[:count, :3].contiguous().numpy())

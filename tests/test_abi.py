@@ -241,9 +241,18 @@ def test_round5_entry_points_validate_before_touching_the_device(nb):
     one = ctypes.c_void_p(16)   # (never dereferenced: the checks come first)
     assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_OWN, None, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
     assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, 0, one, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
-    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, 4, one, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
+    assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_OWN_READY + 1, one, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID
     assert lib.nb_launch_ring_fold_phase(ctypes.byref(strict), 131072, 0, 16384, _lib.NB_RING_REST, one, one, one, 1 << 30, None) == _lib.NB_ERR_UNSUPPORTED
     assert lib.nb_launch_ring_fold_phase(ctypes.byref(fast), 131072, 0, 16384, _lib.NB_RING_REST, one, one, one, 64, None) == _lib.NB_ERR_INVALID   # scratch too small
+    # the fused finish: sums may be NULL (the finish adds the rank's own records), nothing else; never aliased; phased shapes only
+    fin = lib.nb_launch_ring_finish_phase
+    two = ctypes.c_void_p(32)
+    assert fin(ctypes.byref(fast), 131072, 0, 16384, one, one, one, None, one, one, 1 << 30, None) == _lib.NB_ERR_INVALID     # pos_out aliases pos_in
+    assert fin(ctypes.byref(fast), 131072, 0, 16384, one, two, one, None, None, one, 1 << 30, None) == _lib.NB_ERR_INVALID    # no recv
+    assert fin(ctypes.byref(fast), 131072, 0, 16384, one, two, one, None, one, None, 1 << 30, None) == _lib.NB_ERR_INVALID    # no scratch
+    assert fin(ctypes.byref(fast), 131072, 0, 16384, one, two, one, None, one, one, 64, None) == _lib.NB_ERR_INVALID          # scratch too small
+    assert fin(ctypes.byref(fast), 1 << 20, 0, 131072, one, two, one, None, one, one, 1 << 40, None) == _lib.NB_ERR_UNSUPPORTED   # config 5: no phases
+    assert fin(ctypes.byref(strict), 131072, 0, 16384, one, two, one, None, one, one, 1 << 30, None) == _lib.NB_ERR_UNSUPPORTED
     # the exchanges as pulls
     assert lib.nb_peers_blob_bytes() >= 64 * 5
     p = ctypes.c_void_p()

@@ -85,20 +85,26 @@ def _worker(rank, world, port, n, k, out_dir, boids=False, overlap=False, ring=F
                     return real(*a, **kw)
                 return call
 
-            for name in ("ring_fold", "ring_fold_phase", "ring_finish"):
+            real_finish = sc.backend.ring_finish   # (the mirror's fused finish calls it: count the fused one only)
+            for name in ("ring_fold", "ring_fold_phase", "ring_finish", "ring_finish_phase"):
                 setattr(sc.backend, name, logged(name, getattr(sc.backend, name)))
+            if ring_overlap:
+                sc.backend.ring_finish = real_finish
             dist.batch_isend_irecv, dist.all_gather_into_tensor = counting_batch, counting_gather
             sc.step_n(k)
             dist.batch_isend_irecv, dist.all_gather_into_tensor = real_batch, real_gather
             want = sorted([("isend", (rank + d) % world, sc.count * 4) for d in range(1, ring + 1)] +
                           [("irecv", (rank - d) % world, sc.count * 4) for d in range(1, ring + 1)])
             assert sent == [want] * k and gathers == [world * sc.slot * 4] * k, (sent, gathers)
-            # one step: pairs that need no other GPU first (phase 1), every other pair (2), the second exchange as soon as the sums of
-            # the ranks in front exist, the rank's own sums (3) beside it, the finish, the all-gather -- which the NEXT step's first
-            # phase does not wait for
-            per_step = (["phase1", "phase2", "exchange", "phase3", "ring_finish", "gather"] if ring_overlap
+            # one step: pairs that need no other GPU first (phase 1; phase 4 from the second step on: the fused finish left their
+            # planes), every other pair (2), the second exchange as soon as the sums of the ranks in front exist, the rank's own sums (3)
+            # beside it, the fused finish, the all-gather -- which the NEXT step's first phase does not wait for
+            per_step = (["phase4", "phase2", "exchange", "phase3", "ring_finish_phase", "gather"] if ring_overlap
                         else ["ring_fold", "exchange", "ring_finish", "gather"])
-            assert order == per_step * k, order
+            want_order = per_step * k
+            if ring_overlap:
+                want_order[0] = "phase1"
+            assert order == want_order, order
         elif boids:   # boids, n-body, boids: the velocity replica must be rebuilt after the n-body step
             gathers = []
             real = dist.all_gather_into_tensor

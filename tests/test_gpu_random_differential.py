@@ -239,6 +239,10 @@ def test_fast_pairs_form_in_phases_random_problems(nb, oracle, monkeypatch, case
     got_p, got_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1, phases=True)
     again_p, again_v = ring_steps_on_one_gpu(nb, pos, vel, world, p, 1, phases=True)
     assert (bits(got_p) == bits(again_p)).all() and (bits(got_v) == bits(again_v)).all(), what + ": not deterministic"
+    if case % 3 == 0:   # the fused finish, two steps (the second starts on the planes and verdicts the first's finish left): the same bits
+        two = ring_steps_on_one_gpu(nb, pos, vel, world, p, 2, phases=True)
+        two_fused = ring_steps_on_one_gpu(nb, pos, vel, world, p, 2, phases="fused")
+        assert all((bits(x) == bits(y)).all() for x, y in zip(two, two_fused)), what + ": the fused finish"
     ref_p, ref_v = oracle.run(pos, vel, 1, np.float32(p.dt), np.float32(p.G), np.float32(p.bias))
     acc = np.abs(ref_v - vel).max()
     assert np.isfinite(got_v).all(), what + ": a slot in flight was read"

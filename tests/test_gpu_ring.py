@@ -19,7 +19,10 @@ def ring_steps_on_one_gpu(nb, pos, vel, world, params, steps=1, keep=None, phase
     exchange and the all-gather by hand.  Returns (positions, velocities).  keep: a dict that receives the ranks' `sums`.
     phases: False = nb_launch_ring_fold; True = the step in phases (nb_launch_ring_fold_phase) in the order a host with the
     exchanges hidden issues them -- and the phase that may run while the all-gather is still landing gets a snapshot whose OTHER
-    slots are NaN: reading a record that could still be in flight poisons the step."""
+    slots are NaN: reading a record that could still be in flight poisons the step.  "fused": the phases with the fused finish
+    (nb_launch_ring_fold_phase(NB_RING_OWN_READY) / nb_launch_ring_finish_phase): from the second step on the first phase gets NO
+    positions at all (all NaN: its planes are what the finish before left), odd steps add the rank's own records in the finish
+    (records [0, S) of `sums` stay poisoned), even steps run NB_RING_SUMS and hand its records over."""
     import torch
 
     from nenbody_amd.dist import HipBackend
@@ -43,25 +46,36 @@ def ring_steps_on_one_gpu(nb, pos, vel, world, params, steps=1, keep=None, phase
         recv.append(torch.full((D * S, 4), float("nan"), device=dev))
         scratch.append(torch.empty((be.ring_scratch_bytes(params, n, r * S, S),), dtype=torch.uint8, device=dev))
     L = nb._lib
-    for _ in range(steps):
+    fused = phases == "fused"
+    for step in range(steps):
+        in_finish = fused and step % 2 == 0   # the finish adds the rank's own records itself
         for r in range(world):
             if not phases:
                 be.ring_fold(params, n, r * S, S, cur, sums[r], scratch[r])
                 continue
             assert be.ring_phased(params, n, r * S, S)
             only_mine = torch.full_like(cur, float("nan"))
-            only_mine[r * S:(r + 1) * S] = cur[r * S:(r + 1) * S]
             a = (params, n, r * S, S)
-            be.ring_fold_phase(*a, L.NB_RING_OWN, only_mine, sums[r], scratch[r])
+            if fused and step:
+                be.ring_fold_phase(*a, L.NB_RING_OWN_READY, only_mine, sums[r], scratch[r])
+            else:
+                only_mine[r * S:(r + 1) * S] = cur[r * S:(r + 1) * S]
+                be.ring_fold_phase(*a, L.NB_RING_OWN, only_mine, sums[r], scratch[r])
             be.ring_fold_phase(*a, L.NB_RING_REST, cur, sums[r], scratch[r])
             sent = sums[r][S:].clone()   # the sums of the ranks in front are final behind NB_RING_REST: what a host would send now
-            be.ring_fold_phase(*a, L.NB_RING_SUMS, cur, sums[r], scratch[r])
+            if in_finish:
+                sums[r][:S] = float("nan")
+            else:
+                be.ring_fold_phase(*a, L.NB_RING_SUMS, cur, sums[r], scratch[r])
             assert (sent.view(torch.int32) == sums[r][S:].view(torch.int32)).all(), "a later phase touched what had been sent"
         for r in range(world):
             for d in range(1, D + 1):
                 recv[r][(d - 1) * S:d * S] = sums[(r - d) % world][d * S:(d + 1) * S]
         for r in range(world):
-            be.ring_finish(params, n, r * S, S, cur, nxt, vels[r], sums[r], recv[r])
+            if fused:
+                be.ring_finish_phase(params, n, r * S, S, cur, nxt, vels[r], None if in_finish else sums[r], recv[r], scratch[r])
+            else:
+                be.ring_finish(params, n, r * S, S, cur, nxt, vels[r], sums[r], recv[r])
         cur, nxt = nxt, cur
     torch.cuda.synchronize()
     if keep is not None:
@@ -167,6 +181,10 @@ def test_ring_phases_vs_oracle(nb, oracle, monkeypatch, n, world, np_, c4_own, c
     p3, v3 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 3, phases=True)
     p_ref3, v_ref3 = oracle.run(pos, vel, 3)
     assert np.abs(p3 - p_ref3).max() <= 1e-4 and np.abs(v3 - v_ref3).max() <= 1e-5
+    # the fused finish (the rank's own records added there, the next step's first phase on the planes it left): the same additions
+    # in the same order -- the same bits
+    p4, v4 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 3, phases="fused")
+    assert (bits(p3) == bits(p4)).all() and (bits(v3) == bits(v4)).all()
 
 
 @pytest.mark.parametrize("cap", [0, 8])
@@ -193,6 +211,11 @@ def test_ring_phases_decide_their_arithmetic_from_what_they_read(nb, oracle, mon
     fast_close(v, v_ref, vel)
     _, v2 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 1, phases=True)
     assert (bits(v) == bits(v2)).all()
+    # the fused finish stamps the NEXT step's verdicts for the own slot: three steps (a planar slot turns 3-D behind the first -- its
+    # bodies were pulled out of the plane) give the bits of the launches that look at the records themselves
+    p3, v3 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 3, phases=True)
+    p4, v4 = ring_steps_on_one_gpu(nb, pos, vel, world, params, 3, phases="fused")
+    assert np.isfinite(v4).all() and (bits(p3) == bits(p4)).all() and (bits(v3) == bits(v4)).all()
 
 
 def test_shapes_that_run_their_step_in_phases(nb, monkeypatch):
@@ -350,6 +373,6 @@ def test_ring_form_is_deterministic_and_finite_through_the_collapse(nb):
     assert (pa[:, 2] == 0).all()
     # the same in phases (the exchanges behind compute): its own bits, as reproducible, as finite
     pc, vc = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100, phases=True)
-    pd, vd = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100, phases=True)
+    pd, vd = ring_steps_on_one_gpu(nb, pos, vel, world, fast, 100, phases="fused")   # ... and with the fused finish: the same bits
     assert (bits(pc) == bits(pd)).all() and (bits(vc) == bits(vd)).all()
     assert np.isfinite(pc).all() and np.isfinite(vc).all() and (pc[:, 2] == 0).all()

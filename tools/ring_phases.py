@@ -4,8 +4,8 @@
     python -u tools/ring_phases.py [N_TOTAL [WORLDS [C4_OWN_LIST [C4_REST_LIST]]]]      e.g.  131072 2,4,8 0,4,8 0,32,40
 
 For the first and the last rank of every world: the one-launch fold + finish (nb_launch_ring_fold), against the same step as a
-host with the exchanges hidden issues it (OWN, REST, SUMS, finish), and the phases one by one -- OWN is what the all-gather can hide
-behind, SUMS what the second exchange can.
+host with the exchanges hidden issues it (OWN, REST, SUMS, finish; and OWN_READY, REST, the fused finish), and the phases one by
+one -- OWN is what the all-gather can hide behind, SUMS what the second exchange can.
 C4 lists: sub-tiles per workgroup of the own-slot / rest phases to try (0 = the library's choice); NB_RING_CAP from the environment.
 """
 import os
@@ -88,9 +88,21 @@ for world in worlds:
                 def phased():
                     ph(L.NB_RING_OWN); ph(L.NB_RING_REST); ph(L.NB_RING_SUMS); fin()
 
+                # the fused finish: no SUMS launch, and from the second step on no planes launch in front of OWN (the positions
+                # alternate between two replicas as a host's do: each step starts on what the finish before wrote)
+                pp = [cur.clone(), nxt.clone()]
+
+                def fused(first=False):
+                    be.ring_fold_phase(*a, L.NB_RING_OWN if first else L.NB_RING_OWN_READY, pp[0], sums, scratch)
+                    be.ring_fold_phase(*a, L.NB_RING_REST, pp[0], sums, scratch)
+                    be.ring_finish_phase(*a, pp[0], pp[1], v4, None, recv, scratch)
+                    pp.reverse()
+
                 t1, tp = timed(one), timed(phased)
+                fused(first=True)
+                tf = timed(fused)
                 parts = {name: timed(lambda p=p: ph(p)) for name, p in (("OWN", L.NB_RING_OWN), ("REST", L.NB_RING_REST), ("SUMS", L.NB_RING_SUMS))}
                 print(f"  {world} ranks, rank {r}, shard {S} (D={D}), c4 own/rest {c4o or 'dflt'}/{c4r or 'dflt'} cap {os.environ.get('NB_RING_CAP', 'dflt')}: "
-                      f"one launch {t1:.1f} us x{whole / t1:.2f} | in phases {tp:.1f} ({tp - t1:+.1f}) | "
+                      f"one launch {t1:.1f} us x{whole / t1:.2f} | in phases {tp:.1f} ({tp - t1:+.1f}) | with the fused finish {tf:.1f} ({tf - t1:+.1f}) | "
                       + " ".join(f"{k} {v:.1f}" for k, v in parts.items()) + f" | finish {timed(fin):.1f}", flush=True)
             del sums, recv
