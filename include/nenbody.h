@@ -426,7 +426,8 @@ int nb_shard_set_overlap(nb_shard *sh, int on);
  * anything: the all-gather from a copy of the slot (*gather_path 1; 0: in place), the second exchange as one group per distance
  * (*ring_path 1; 0: one group), then not at all (*ring_path 2: the ordered fold and its one exchange); *ring_path -1: no pairs form
  * planned.  A shard that pulls its exchanges over xGMI (nb_shard_peer_import) is checked as such first (*gather_path 2, *ring_path 3)
- * and goes back to the exchange chosen before on a mismatch.  Either pointer may be NULL.  A world of one answers at once.  With RCCL on more than one rank the first nb_shard_step runs
+ * -- TWICE from the same buffers with different patterns: a reader served from lines it cached at the first pull shows the first pattern
+ * again -- and goes back to the exchange chosen before on a mismatch.  Either pointer may be NULL.  A world of one answers at once.  With RCCL on more than one rank the first nb_shard_step runs
  * this by itself if the host has not. */
 int nb_shard_verify_exchanges(nb_shard *sh, int *gather_path, int *ring_path);
 /* Which form should a FAST step take on THIS machine?  Times `steps` steps (0: four) of every form the shard can take -- 1: the pairs

@@ -87,8 +87,10 @@ int nb_diag_rccl_solo(int on);
  * workgroup-tile FAST form, wave counts other than eight, ...). */
 int nb_diag_legacy_forms(void);
 
-/* on != 0: rank 0's pulls over xGMI (nb_peers_gather / nb_peers_ring) lose their first record -- what a peer's stores not being visible
- * when its flag says so would look like.  A process switch for the test suite: the fallbacks of verify_exchanges on a one-GPU box. */
+/* on == 1: rank 0's pulls over xGMI (nb_peers_gather / nb_peers_ring) lose their first record -- what a peer's stores not being visible
+ * when its flag says so would look like.  on == 2: the first pull of each kind is whole, every later one copies nothing -- a reader served
+ * from a cache it filled earlier (verify_exchanges checks the pulls twice from the same buffers for this).  0: off.  A process switch for
+ * the test suite: the fallbacks of verify_exchanges on a one-GPU box. */
 int nb_diag_peers_lossy(int on);
 
 /* The kernels one step of this shape launches, dominant one first, comma separated ("step_strict_bc_kernel,planes_kernel"),

@@ -434,16 +434,24 @@ class ShardedScene:
 
         # -- the all-gather: every slot of the buffer must hold its rank's pattern
         buf = self.pos[self.cur ^ 1]
-        want = torch.cat([pattern(r, self.slot, 7.0) for r in range(self.world)])
-        # (with pulls over xGMI the first attempt is the pulls; a mismatch sends BOTH exchanges back to the collectives)
+        # (with pulls over xGMI the first attempt is the pulls; a mismatch sends BOTH exchanges back to the collectives.  The pulls are
+        # checked TWICE from the same buffers with different patterns: a reader that kept lines of a peer's memory in a cache would pass
+        # the first round and show the first pattern again in the second.  The agreement between the rounds is also the barrier that
+        # lets a rank rewrite a buffer its peers have pulled from.)
         for attempt in (("peers",) if self.exchange == "peers" else ()) + ("in_place", "out_of_place"):
             if attempt != "peers":
                 self.exchange = "collective"
             self.gather_in_place = attempt != "out_of_place"
-            buf.fill_(float("nan"))
-            buf[self.rank * self.slot:(self.rank + 1) * self.slot] = want[self.rank * self.slot:(self.rank + 1) * self.slot]
-            self._all_gather_slots(buf)
-            if not agree(not torch.equal(buf, want)):
+            bad = False
+            for salt in (7.0, 9.0) if attempt == "peers" else (7.0,):
+                want = torch.cat([pattern(r, self.slot, salt) for r in range(self.world)])
+                buf.fill_(float("nan"))
+                buf[self.rank * self.slot:(self.rank + 1) * self.slot] = want[self.rank * self.slot:(self.rank + 1) * self.slot]
+                self._all_gather_slots(buf)
+                bad = agree(not torch.equal(buf, want))
+                if bad:
+                    break
+            if not bad:
                 rep["all_gather"] = attempt
                 break
         buf.zero_()
@@ -452,17 +460,22 @@ class ShardedScene:
         # -- the pairs form's second exchange: chunk d - 1 of recv must hold chunk d of rank - d's sums
         if self.partners:
             S = self.count
-            want = torch.cat([pattern((self.rank - d) % self.world, S, float(d)) for d in range(1, self.partners + 1)])
             for attempt in (("peers",) if self.exchange == "peers" and self._peers_sums else ()) + ("grouped", "per_distance"):
                 if attempt != "peers" and self.exchange == "peers":
                     self.exchange = "collective"   # (the all-gather goes back too: one kind of exchange per step; it was verified above as pulls, the collective is re-verified by the next call)
                 self.ring_grouped = attempt != "per_distance"
-                self.sums[:S].zero_()
-                for d in range(1, self.partners + 1):
-                    self.sums[d * S:(d + 1) * S] = pattern(self.rank, S, float(d))
-                self.recv.fill_(float("nan"))
-                self._ring_exchange()
-                if not agree(not torch.equal(self.recv, want)):
+                bad = False
+                for salt in (0.0, 16.0) if attempt == "peers" else (0.0,):   # (pulls: twice from the same buffers, as above)
+                    want = torch.cat([pattern((self.rank - d) % self.world, S, salt + d) for d in range(1, self.partners + 1)])
+                    self.sums[:S].zero_()
+                    for d in range(1, self.partners + 1):
+                        self.sums[d * S:(d + 1) * S] = pattern(self.rank, S, salt + d)
+                    self.recv.fill_(float("nan"))
+                    self._ring_exchange()
+                    bad = agree(not torch.equal(self.recv, want))
+                    if bad:
+                        break
+                if not bad:
                     rep["ring_exchange"] = attempt
                     break
             if rep["ring_exchange"] is None:   # neither form delivers: the ordered fold and its one exchange

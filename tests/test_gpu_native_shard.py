@@ -213,8 +213,9 @@ def _rank_worker(rank, world, port, n, mode, out_dir, overlap=False, schedule=No
                                      gather=None if peers == "only" else gather, overlap=overlap, ring=ring if (with_ring and peers != "only") else None,
                                      peers=swap_blobs if peers else None) as sh:
             extra = {}
-            if verify == "lossy_pulls":   # pulls that lose a record on rank 0: every rank goes back to the host's exchanges, in both
-                nenbody_amd.load().nb_diag_peers_lossy(1)
+            if verify in ("lossy_pulls", "stale_pulls"):   # pulls that lose a record on rank 0 / that deliver the first time only (the second
+                # pattern round catches those): every rank goes back to the host's exchanges, in both
+                nenbody_amd.load().nb_diag_peers_lossy(1 if verify == "lossy_pulls" else 2)
                 try:
                     assert sh.verify_exchanges() == (0, 0 if sh.partners else -1)
                 finally:
@@ -401,9 +402,11 @@ def test_shards_that_pull_their_exchanges_over_ipc(tmp_path, nb, oracle, world, 
             assert np.quantile(dp, 0.999) <= 4e-4 * scale and dp.max() <= 4e-2 * scale, f"rank {r} positions (replica)"
 
 
-def test_pulls_that_lose_data_send_both_exchanges_back_to_the_hosts(tmp_path, nb, oracle):
-    """nb_shard_verify_exchanges on a shard that pulls its exchanges over IPC, with rank 0's pulls made lossy (nb_diag_peers_lossy: the
-    first record of what it pulls is overwritten -- what stores that are not visible when their flag says so would look like): every
+@pytest.mark.parametrize("fault", ["lossy_pulls", "stale_pulls"])
+def test_pulls_that_lose_data_send_both_exchanges_back_to_the_hosts(tmp_path, nb, oracle, fault):
+    """nb_shard_verify_exchanges on a shard that pulls its exchanges over IPC, with rank 0's pulls made lossy (nb_diag_peers_lossy 1: the
+    first record of what it pulls is overwritten -- what stores that are not visible when their flag says so would look like; 2: only
+    the first pull of each kind copies anything -- a reader served from a cache; the second pattern round is there for it): every
     rank must see the verdict and go back to the exchanges chosen before (here the host's gather and ring functions), and the steps
     that follow run through those and are right."""
     import torch.multiprocessing as mp
@@ -412,7 +415,7 @@ def test_pulls_that_lose_data_send_both_exchanges_back_to_the_hosts(tmp_path, nb
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(tmp_path), False, schedule, True, 77, True, "lossy_pulls", True), nprocs=world, join=True)
+    mp.spawn(_rank_worker, args=(world, port, n, nb.NB_MODE_FAST, str(tmp_path), False, schedule, True, 77, True, fault, True), nprocs=world, join=True)
     pos, vel = oracle.init_state(n, 77)
     p_ref, v_ref = reference(oracle, pos, vel, schedule)
     scale = float(np.abs(v_ref - vel).max())

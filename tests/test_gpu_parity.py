@@ -1333,9 +1333,10 @@ def _peers_worker(rank, world, port, n, k, mode, out_dir, what):
             assert sc.exchange_report["all_gather"] == "peers" and sc.exchange_report["verified"]
             assert (sc.positions() == before[0]).all() and (sc.velocities() == before[1]).all()
             sc.step_n(k - 1)
-        elif what == "ring_lossy":   # rank 0's pulls lose a record: every rank goes back to the collectives for both exchanges
+        elif what in ("ring_lossy", "ring_stale"):   # rank 0's pulls lose a record / deliver only the first time (a stale cache: the SECOND
+            # pattern round catches it): every rank goes back to the collectives for both exchanges
             sc = nenbody_amd.ShardedScene(pos, vel, p, exchange="peers", ring=True)
-            nenbody_amd.load().nb_diag_peers_lossy(1)
+            nenbody_amd.load().nb_diag_peers_lossy(1 if what == "ring_lossy" else 2)
             try:
                 rep = sc.verify_exchanges()
             finally:
@@ -1362,14 +1363,14 @@ def _peers_worker(rank, world, port, n, k, mode, out_dir, what):
 
 
 @pytest.mark.parametrize("world,n,what", [(2, 4096, "strict"), (3, 1000, "strict"), (3, 20000, "overlap"), (4, 16384, "ring"), (4, 16384, "ring_overlap"),
-                                          (2, 8192, "ring_overlap"), (3, 4096, "choose"), (4, 16384, "ring_lossy")])
+                                          (2, 8192, "ring_overlap"), (3, 4096, "choose"), (4, 16384, "ring_lossy"), (4, 16384, "ring_stale")])
 def test_sharded_scene_pulls_its_exchanges_over_ipc(tmp_path, nb, oracle, world, n, what):
     """ShardedScene(exchange="peers"): the all-gather and the pairs form's second exchange as pulls over IPC-mapped buffers, ordered by
     stream value waits (nb_peers_*), between PROCESSES sharing the one GPU; torch.distributed only carries the handles.  Every step
     is checked not to touch a collective; STRICT (a ragged world too) bit-identical to the oracle, the FAST forms -- ordered fold with
     the pull behind the own slot's fold, the pairs form in sequence and in phases -- at FAST's tolerance; verify_exchanges reports the
-    pulls verified; choose_exchange times them against the collectives and puts the state back; pulls made lossy on one rank
-    (nb_diag_peers_lossy) send every rank back to the collectives."""
+    pulls verified; choose_exchange times them against the collectives and puts the state back; pulls made lossy on one rank, or whole
+    the first time only (nb_diag_peers_lossy 1 / 2), send every rank back to the collectives."""
     import socket
 
     import torch.multiprocessing as mp
