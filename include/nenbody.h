@@ -347,7 +347,7 @@ int nb_launch_unpack(uint32_t count, const void *rec4, void *xyz, void *stream);
 typedef struct nb_peers nb_peers;
 size_t nb_peers_blob_bytes(void);
 int nb_peers_create(int rank, int world, nb_peers **out);
-void nb_peers_destroy(nb_peers *p);
+void nb_peers_destroy(nb_peers *p);   /* (after a probe that had to abandon its stream: releases nothing -- every release would wait for that stream) */
 const char *nb_peers_last_error(const nb_peers *p);
 int nb_peers_export(nb_peers *p, void *const *bufs, const size_t *bytes, int nbufs, void *blob);
 int nb_peers_import(nb_peers *p, const void *blobs /* world x nb_peers_blob_bytes(), rank-major */);
