@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# Memory handles between the ranks' processes (RCCL's own, and the pulls of nb_peers_*) need the dmabuf IPC mode on this platform: the
+# image exports it; a launcher that builds its own environment may not.  Before anything touches the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
